@@ -1,0 +1,173 @@
+// Weight gradient of the 3x3 / 1x1 / Linear layers on the fp32-input MFMA (gfx950).
+//
+//   dWp[co][tap][ci] += sum_{p in split} dY[p][co] * X[pix(p) + tap][ci]
+//
+// GEMM view: M' = Cout (rows of dY^T), N' = Cin, K' = pixels.  Both operands arrive pixel-major
+// (NHWC), i.e. "k-major" with the m / n index contiguous, so tiles are staged into LDS exactly as
+// they lie in memory ([32 pixels][TM] and [32 pixels][TN]) and MFMA fragments are read with
+// conflict-free ds_read_b32 (lane = consecutive channel; the two wave halves read pixel 2s and 2s+1).
+// The reduction over pixels is split across gridDim.z; partial tiles are combined with fp32 global
+// atomics shaped as 128-byte row segments (the full-rate shape on MI355X), or plain stores when
+// splits == 1.  Autograd counterpart of F.conv2d's weight gradient in the reference
+// (/root/reference/unet/uncond_unet.py:98-110 under loss.backward()).
+#include "common.h"
+#include "../../include/adm_hip.h"
+
+namespace {
+
+struct WgradP {
+  const float* x; const float* dy; float* dwp;
+  int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int MT = TM / (WM * 32), NT = TN / (WN * 32);
+  constexpr int AQ = TM / 4, BQ = TN / 4;              // float4 per tile row
+  constexpr int AR = 256 / AQ, BR = 256 / BQ;          // rows covered per pass
+  constexpr int AI = 32 / AR, BI = 32 / BR;            // passes
+  __shared__ __attribute__((aligned(16))) float As[2][32][TM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][32][TN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+  const int co0 = tm * TM, ci0 = tn * TN;
+  const int tap = blockIdx.y;
+  const int pad = p.ks >> 1;
+  const int dy_ = (p.ks == 3) ? tap / 3 - pad : 0, dx_ = (p.ks == 3) ? tap % 3 - pad : 0;
+  const int pbeg = blockIdx.z * p.chunk;
+  const int pend = min(p.P, pbeg + p.chunk);
+  if (pbeg >= pend) return;
+  const int KT = (pend - pbeg + 31) >> 5;
+
+  const int a_c = tid % AQ, a_r = tid / AQ;
+  const int b_c = tid % BQ, b_r = tid / BQ;
+  const bool a_cok = co0 + a_c * 4 < p.Cout;
+  const bool b_cok = ci0 + b_c * 4 < p.Cin;
+
+  f32x4 ra[AI], rb[BI];
+  auto load_stage = [&](int s) {
+    const int pb = pbeg + (s << 5);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int pp = pb + a_r + i * AR;
+      bool v = a_cok && pp < pend;
+      ra[i] = v ? *reinterpret_cast<const f32x4*>(p.dy + (long)pp * p.lddy + co0 + a_c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int pp = pb + b_r + i * BR;
+      bool v = b_cok && pp < pend;
+      int ppp = v ? pp : 0;
+      int ox = ppp % p.W;
+      int t = ppp / p.W;
+      int oy = t % p.H;
+      int b = t / p.H;
+      int iy = oy + dy_, ix = ox + dx_;
+      v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      if (p.up) { iy >>= 1; ix >>= 1; }
+      const float* ptr = p.x + ((long)(b * p.Hin + iy) * p.Win + ix) * p.ldx + ci0 + b_c * 4;
+      rb[i] = v ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[buf][a_r + i * AR][a_c * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][b_r + i * BR][b_c * 4]) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < KT; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < KT) load_stage(s + 1);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = As[buf][2 * k + lh][(wm * MT + i) * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = Bs[buf][2 * k + lh][(wn * NT + j) * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < KT) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int taps = p.ks * p.ks;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ci = ci0 + (wn * NT + j) * 32 + lr;
+    if (ci >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int cb = co0 + (wm * MT + i) * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb + (r & 3) + 8 * (r >> 2);
+        if (co < p.Cout) {
+          float* dst = p.dwp + ((long)co * taps + tap) * p.Cin + ci;
+          if (p.atomic) atomicAdd(dst, acc[i][j][r]);
+          else *dst = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+int launch_wgrad(WgradP p, int splits, hipStream_t st) {
+  p.tilesN = adm_cdiv(p.Cin, TN);
+  dim3 grid(adm_cdiv(p.Cout, TM) * p.tilesN, p.ks * p.ks, splits);
+  hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN>), grid, dim3(256), 0, st, p);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+}  // namespace
+
+extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
+                              int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
+  if (!x || !dy || !dwp || B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
+  if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3) || (ks != 1 && ks != 3)) return ADM_EINVAL;
+  if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)dy) & 15) return ADM_EINVAL;
+  WgradP p;
+  p.x = x; p.dy = dy; p.dwp = dwp;
+  p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
+  p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.ks = ks; p.up = up; p.tilesN = 0;
+  const int TM = (Cout % 128 == 0) ? 128 : 64;
+  const int TN = (Cin % 128 == 0) ? 128 : 64;
+  if (splits <= 0) {   // aim for >= ~512 workgroups, keep >= 256 pixels per split
+    long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
+    splits = (int)((512 + tiles - 1) / tiles);
+    int maxs = (p.P + 255) / 256;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  int chunk = ((p.P + splits - 1) / splits + 31) & ~31;
+  splits = (p.P + chunk - 1) / chunk;
+  p.chunk = chunk;
+  p.atomic = splits > 1;
+  if (TM == 128 && TN == 128) return launch_wgrad<128, 128>(p, splits, stream);
+  if (TM == 128 && TN == 64) return launch_wgrad<128, 64>(p, splits, stream);
+  if (TM == 64 && TN == 128) return launch_wgrad<64, 128>(p, splits, stream);
+  return launch_wgrad<64, 64>(p, splits, stream);
+}

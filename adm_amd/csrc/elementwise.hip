@@ -1,0 +1,504 @@
+// HBM-bound elementwise / small-reduction kernels of the DDM hot path: resampling, layout +
+// preconditioning, time embedding, SpatialAtt gate, analytic-schedule updates, loss, optimiser.
+// All are simple grid-stride kernels with 16-byte accesses where the layout allows.
+#include "common.h"
+#include "../../include/adm_hip.h"
+
+namespace {
+
+inline int ew_grid(long n, int per_thread = 1) {
+  long b = (n / per_thread + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 8192) b = 8192;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- resample
+__global__ void down2x_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int B, int Ho, int Wo, int C4,
+                              float scale, int acc) {
+  long total = (long)B * Ho * Wo * C4;
+  const int Wi = Wo * 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % C4;
+    long t = i / C4;
+    int ox = t % Wo; t /= Wo;
+    int oy = t % Ho;
+    int b = t / Ho;
+    long base = (((long)b * Ho * 2 + oy * 2) * Wi + ox * 2) * C4 + c;
+    f32x4 v = (x[base] + x[base + C4] + x[base + (long)Wi * C4] + x[base + (long)Wi * C4 + C4]) * scale;
+    y[i] = acc ? y[i] + v : v;
+  }
+}
+__global__ void up2x_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int B, int Hi, int Wi, int C4,
+                            float scale, int acc) {
+  const int Ho = Hi * 2, Wo = Wi * 2;
+  long total = (long)B * Ho * Wo * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % C4;
+    long t = i / C4;
+    int ox = t % Wo; t /= Wo;
+    int oy = t % Ho;
+    int b = t / Ho;
+    f32x4 v = x[(((long)b * Hi + (oy >> 1)) * Wi + (ox >> 1)) * C4 + c] * scale;
+    y[i] = acc ? y[i] + v : v;
+  }
+}
+
+// ---------------------------------------------------------------- layout / preconditioning
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const T* __restrict__ x, const float* __restrict__ mul, long mul_bstride,
+                                    float* __restrict__ y, int B, int C, int HW, int Cpad) {
+  long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int p = i % HW;
+    int b = i / HW;
+    float m = mul ? mul[b * mul_bstride] : 1.f;
+    float* o = y + i * Cpad;
+    for (int c = 0; c < Cpad; ++c) o[c] = c < C ? m * (float)x[((long)b * C + c) * HW + p] : 0.f;
+  }
+}
+template <typename T>
+__global__ void precond_out_kernel(const T* __restrict__ x, const float* __restrict__ f, int ldf,
+                                   const float* __restrict__ a, const float* __restrict__ s, long cbs,
+                                   float* __restrict__ out, int B, int C, int HW) {
+  long total = (long)B * C * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int p = i % HW;
+    long t = i / HW;
+    int c = t % C;
+    int b = t / C;
+    out[i] = a[b * cbs] * (float)x[i] + s[b * cbs] * f[((long)b * HW + p) * ldf + c];
+  }
+}
+__global__ void precond_out_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ s, long cbs,
+                                       float* __restrict__ df, int ldf, int B, int C, int HW) {
+  long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int p = i % HW;
+    int b = i / HW;
+    float sv = s[b * cbs];
+    float* o = df + i * ldf;
+    for (int c = 0; c < ldf; ++c) o[c] = c < C ? sv * dout[((long)b * C + c) * HW + p] : 0.f;
+  }
+}
+template <typename T>
+__global__ void axpby_b_kernel(const T* __restrict__ x, const float* __restrict__ y, const float* __restrict__ a,
+                               const float* __restrict__ s, long cbs, float* __restrict__ out, int B, long n) {
+  long total = (long)B * n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int b = i / n;
+    float v = s[b * cbs] * y[i];
+    if (x) v += a[b * cbs] * (float)x[i];
+    out[i] = v;
+  }
+}
+
+__global__ void pos_embedding_kernel(const float* __restrict__ t, float* __restrict__ emb, int B, int C) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int half = C / 2;
+  if (i >= B * half) return;
+  int b = i / half, k = i - b * half;
+  float f = powf(1.0f / 10000.0f, (float)k / (float)half);
+  float ang = t[b] * f;
+  emb[(long)b * C + k] = cosf(ang);
+  emb[(long)b * C + half + k] = sinf(ang);
+}
+
+__global__ void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = silu_f(x[i]);
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * silu_grad_f(x[i]);
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
+}
+__global__ void copy_channels_kernel(const float* __restrict__ src, int lds_, int src_off, float* __restrict__ dst,
+                                     int ldd, int dst_off, long M, int C4, float scale, int acc) {
+  long total = M * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % C4;
+    long m = i / C4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + m * lds_ + src_off + c * 4) * scale;
+    f32x4* d = reinterpret_cast<f32x4*>(dst + m * ldd + dst_off + c * 4);
+    *d = acc ? *d + v : v;
+  }
+}
+
+// ---------------------------------------------------------------- SpatialAtt gate
+// one block per batch element; HW <= 64
+__global__ __launch_bounds__(256) void spatial_att_fwd_kernel(const float* __restrict__ att, int ldatt,
+                                                              const float* __restrict__ qk,
+                                                              const float* __restrict__ h,
+                                                              const float* __restrict__ xres, float* __restrict__ y,
+                                                              int HW, int C) {
+  __shared__ float a_s[64], g_s[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < HW) a_s[tid] = att[((long)b * HW + tid) * ldatt];
+  __syncthreads();
+  if (tid < HW) {
+    const float qw = qk[0], qb = qk[1], kw = qk[2], kb = qk[3];
+    float q = qw * a_s[tid] + qb;
+    float m = -INFINITY;
+    for (int j = 0; j < HW; ++j) m = fmaxf(m, q * (kw * a_s[j] + kb));
+    float l = 0.f, acc = 0.f;
+    for (int j = 0; j < HW; ++j) {
+      float e = __expf(q * (kw * a_s[j] + kb) - m);
+      l += e; acc += e * a_s[j];
+    }
+    float a = acc / l;
+    g_s[tid] = a / (1.f + fabsf(a));
+  }
+  __syncthreads();
+  const int C4 = C >> 2;
+  const f32x4* hb = reinterpret_cast<const f32x4*>(h + (long)b * HW * C);
+  const f32x4* xb = reinterpret_cast<const f32x4*>(xres + (long)b * HW * C);
+  f32x4* yb = reinterpret_cast<f32x4*>(y + (long)b * HW * C);
+  for (int i = tid; i < HW * C4; i += blockDim.x) yb[i] = hb[i] * g_s[i / C4] + xb[i];
+}
+
+__global__ __launch_bounds__(256) void spatial_att_bwd_kernel(const float* __restrict__ att, int ldatt,
+                                                              const float* __restrict__ qk,
+                                                              const float* __restrict__ h,
+                                                              const float* __restrict__ dy, float* __restrict__ dh,
+                                                              float* __restrict__ datt, float* __restrict__ dqk,
+                                                              int HW, int C) {
+  __shared__ float a_s[64], g_s[64], av_s[64], dg_s[64], da_s[64], dq_s[64], dk_s[64], p_s[64][65];
+  __shared__ float part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float qw = qk[0], qb = qk[1], kw = qk[2], kb = qk[3];
+  if (tid < HW) a_s[tid] = att[((long)b * HW + tid) * ldatt];
+  __syncthreads();
+  if (tid < HW) {
+    float q = qw * a_s[tid] + qb;
+    float m = -INFINITY;
+    for (int j = 0; j < HW; ++j) m = fmaxf(m, q * (kw * a_s[j] + kb));
+    float l = 0.f, acc = 0.f;
+    for (int j = 0; j < HW; ++j) {
+      float e = __expf(q * (kw * a_s[j] + kb) - m);
+      p_s[tid][j] = e; l += e; acc += e * a_s[j];
+    }
+    float inv = 1.f / l;
+    for (int j = 0; j < HW; ++j) p_s[tid][j] *= inv;
+    float a = acc * inv;
+    av_s[tid] = a;
+    g_s[tid] = a / (1.f + fabsf(a));
+  }
+  __syncthreads();
+  // dh = g * dy ; dg_i = sum_c dy h   (4 threads per pixel row when HW <= 64)
+  const int C4 = C >> 2;
+  const f32x4* hb = reinterpret_cast<const f32x4*>(h + (long)b * HW * C);
+  const f32x4* gb = reinterpret_cast<const f32x4*>(dy + (long)b * HW * C);
+  f32x4* ob = reinterpret_cast<f32x4*>(dh + (long)b * HW * C);
+  const int tpr = blockDim.x / 64;                 // threads per row
+  {
+    int row = tid / tpr, sub = tid % tpr;
+    float acc = 0.f;
+    if (row < HW)
+      for (int c = sub; c < C4; c += tpr) {
+        f32x4 d = gb[row * C4 + c], hv = hb[row * C4 + c];
+        ob[row * C4 + c] = d * g_s[row];
+        acc += d[0] * hv[0] + d[1] * hv[1] + d[2] * hv[2] + d[3] * hv[3];
+      }
+    part[tid] = acc;
+  }
+  __syncthreads();
+  if (tid < HW) {
+    float dg = 0.f;
+    for (int s = 0; s < tpr; ++s) dg += part[tid * tpr + s];
+    float d1 = 1.f + fabsf(av_s[tid]);
+    dg_s[tid] = dg;
+    da_s[tid] = dg / (d1 * d1);
+  }
+  __syncthreads();
+  if (tid < HW) {      // as query i = tid: dq_i = sum_j ds_ij k_j
+    float dq = 0.f;
+    for (int j = 0; j < HW; ++j) dq += p_s[tid][j] * da_s[tid] * (a_s[j] - av_s[tid]) * (kw * a_s[j] + kb);
+    dq_s[tid] = dq;
+  }
+  if (tid >= 64 && tid < 64 + HW) {   // as key j: dk_j = sum_i ds_ij q_i ; datt_j (direct) = sum_i p_ij da_i
+    int j = tid - 64;
+    float dk = 0.f, dat = 0.f;
+    for (int i = 0; i < HW; ++i) {
+      float ds = p_s[i][j] * da_s[i] * (a_s[j] - av_s[i]);
+      dk += ds * (qw * a_s[i] + qb);
+      dat += p_s[i][j] * da_s[i];
+    }
+    dk_s[j] = dk;
+    part[j] = dat;
+  }
+  __syncthreads();
+  if (tid < HW) {
+    float dat = part[tid] + qw * dq_s[tid] + kw * dk_s[tid];
+    float* o = datt + ((long)b * HW + tid) * ldatt;
+    o[0] = dat;
+    for (int c = 1; c < ldatt; ++c) o[c] = 0.f;
+  }
+  if (tid == 0) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = 0; i < HW; ++i) {
+      s0 += dq_s[i] * a_s[i]; s1 += dq_s[i];
+      s2 += dk_s[i] * a_s[i]; s3 += dk_s[i];
+    }
+    atomicAdd(&dqk[0], s0); atomicAdd(&dqk[1], s1); atomicAdd(&dqk[2], s2); atomicAdd(&dqk[3], s3);
+  }
+}
+
+// ---------------------------------------------------------------- analytic schedule
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                const float* __restrict__ t, float* __restrict__ xt, int B, long n, int schedule) {
+  long total = (long)B * n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float tt = t[i / n];
+    float g = schedule == 0 ? sqrtf(tt) : tt;
+    float x = x0[i];
+    float c = -1.f * x;
+    xt[i] = x + c * tt + g * noise[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void ddm_loss_kernel(const float* __restrict__ cp, const float* __restrict__ np_,
+                                                       const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const float* __restrict__ w, float* __restrict__ per_sample,
+                                                       float* __restrict__ dc, float* __restrict__ dn, float gscale,
+                                                       long n) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float w1 = w[2 * b], w2 = w[2 * b + 1];
+  float acc = 0.f;
+  for (long i = blockIdx.y * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.y * blockDim.x) {
+    long k = (long)b * n + i;
+    float e1 = cp[k] + x0[k];          // C_pred - C, C = -x0
+    float e2 = np_[k] - noise[k];
+    acc += w1 * e1 * e1 + w2 * e2 * e2;
+    if (dc) { dc[k] = gscale * 2.f * w1 * e1; dn[k] = gscale * 2.f * w2 * e2; }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&per_sample[b], red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void sampler_step_kernel(double* __restrict__ x, const float* __restrict__ cp, const float* __restrict__ np_,
+                                    double t_cur, double t_next, double g_cur, double g_next, int clip_x0,
+                                    double scale_input, int last, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double c = (double)cp[i], e = (double)np_[i];
+    double x0 = x[i] - c * t_cur - e * g_cur;
+    if (clip_x0) x0 = fmin(fmax(x0, -scale_input), scale_input);
+    double xn = x0 + c * t_next + e * g_next;
+    if (last) {
+      xn = fmin(fmax(xn, -scale_input), scale_input);
+      if (scale_input != 1.0) xn = xn / scale_input;
+      xn = (xn + 1.0) * 0.5;
+    }
+    x[i] = xn;
+  }
+}
+
+// ---------------------------------------------------------------- optimiser
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, double* __restrict__ out, long n) {
+  __shared__ double red[4];
+  float acc = 0.f;
+  long n4 = n >> 2;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = g4[i];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[(n4 << 2) + threadIdx.x]; acc += v * v; }
+  double d = wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, float* __restrict__ ema, const double* __restrict__ sumsq, long n,
+                             float lr, float b1, float b2, float eps, float wd, float max_norm, float bc1, float bc2s,
+                             float ema_w, float grad_scale) {
+  float clip = 1.f;
+  if (sumsq && max_norm > 0.f) {
+    float nrm = (float)sqrt(*sumsq) * grad_scale;
+    clip = fminf(1.f, max_norm / (nrm + 1e-6f));
+  }
+  const float gs = clip * grad_scale;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gv = g[i] * gs;
+    float pv = p[i] * (1.f - lr * wd);
+    float mv = b1 * m[i] + (1.f - b1) * gv;
+    float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv; v[i] = vv;
+    float denom = sqrtf(vv) / bc2s + eps;
+    pv -= (lr / bc1) * (mv / denom);
+    p[i] = pv;
+    if (ema) ema[i] += ema_w * (pv - ema[i]);
+  }
+}
+
+}  // namespace
+
+extern "C" int adm_version(void) { return 1; }
+
+extern "C" int adm_resample2x(const float* x, float* y, int B, int H, int W, int C, int mode, float scale, int acc,
+                              hipStream_t stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || (C & 3)) return ADM_EINVAL;
+  if (mode == 0) {
+    if ((H & 1) || (W & 1)) return ADM_EINVAL;
+    long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(down2x_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, (const f32x4*)x, (f32x4*)y, B, H / 2,
+                       W / 2, C / 4, scale, acc);
+  } else if (mode == 1) {
+    long total = (long)B * H * 2 * W * 2 * (C / 4);
+    hipLaunchKernelGGL(up2x_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, (const f32x4*)x, (f32x4*)y, B, H, W,
+                       C / 4, scale, acc);
+  } else return ADM_EINVAL;
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_nchw_to_nhwc(const void* x, int x_is_f64, const float* mul, long mul_bstride, float* y, int B, int C,
+                                int HW, int Cpad, hipStream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || Cpad < C) return ADM_EINVAL;
+  int grid = ew_grid((long)B * HW);
+  if (x_is_f64)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)x, mul, mul_bstride, y, B, C, HW, Cpad);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, mul, mul_bstride, y, B, C, HW, Cpad);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_precond_out(const void* x, int x_is_f64, const float* f, int ldf, const float* a, const float* s,
+                               long coef_bstride, float* out, int B, int C, int HW, hipStream_t stream) {
+  if (!x || !f || !a || !s || !out || B <= 0 || C <= 0 || HW <= 0 || ldf < C) return ADM_EINVAL;
+  int grid = ew_grid((long)B * C * HW);
+  if (x_is_f64)
+    hipLaunchKernelGGL(precond_out_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)x, f, ldf, a, s, coef_bstride, out, B, C, HW);
+  else
+    hipLaunchKernelGGL(precond_out_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, f, ldf, a, s, coef_bstride, out, B, C, HW);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_precond_out_bwd(const float* dout, const float* s, long coef_bstride, float* df, int ldf, int B,
+                                   int C, int HW, hipStream_t stream) {
+  if (!dout || !s || !df || B <= 0 || C <= 0 || HW <= 0 || ldf < C) return ADM_EINVAL;
+  hipLaunchKernelGGL(precond_out_bwd_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, stream, dout, s, coef_bstride, df, ldf, B, C, HW);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_axpby_b(const void* x, int x_is_f64, const float* y, const float* a, const float* s,
+                           long coef_bstride, float* out, int B, long n, hipStream_t stream) {
+  if (!y || !s || !out || B <= 0 || n <= 0 || (x && !a)) return ADM_EINVAL;
+  int grid = ew_grid((long)B * n);
+  if (x_is_f64)
+    hipLaunchKernelGGL(axpby_b_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)x, y, a, s, coef_bstride, out, B, n);
+  else
+    hipLaunchKernelGGL(axpby_b_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, y, a, s, coef_bstride, out, B, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_pos_embedding(const float* t, float* emb, int B, int C, hipStream_t stream) {
+  if (!t || !emb || B <= 0 || C <= 0 || (C & 1)) return ADM_EINVAL;
+  hipLaunchKernelGGL(pos_embedding_kernel, dim3(adm_cdiv((long)B * C / 2, 256)), dim3(256), 0, stream, t, emb, B, C);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_silu_fwd(const float* x, float* y, long n, hipStream_t stream) {
+  if (!x || !y || n <= 0) return ADM_EINVAL;
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, y, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+extern "C" int adm_silu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t stream) {
+  if (!x || !dy || !dx || n <= 0) return ADM_EINVAL;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, dy, dx, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+extern "C" int adm_add(const float* a, const float* b, float* y, long n, hipStream_t stream) {
+  if (!a || !b || !y || n <= 0) return ADM_EINVAL;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, a, b, y, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+extern "C" int adm_copy_channels(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
+                                 float scale, int acc, hipStream_t stream) {
+  if (!src || !dst || M <= 0 || C <= 0 || (C & 3) || (lds & 3) || (ldd & 3) || (src_off & 3) || (dst_off & 3))
+    return ADM_EINVAL;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, stream, src, lds, src_off, dst, ldd,
+                     dst_off, M, C / 4, scale, acc);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_spatial_att_fwd(const float* att, int ldatt, const float* qk, const float* h, const float* xres,
+                                   float* y, int B, int HW, int C, hipStream_t stream) {
+  if (!att || !qk || !h || !xres || !y || B <= 0 || HW <= 0 || HW > 64 || (C & 3)) return ADM_EINVAL;
+  hipLaunchKernelGGL(spatial_att_fwd_kernel, dim3(B), dim3(256), 0, stream, att, ldatt, qk, h, xres, y, HW, C);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+extern "C" int adm_spatial_att_bwd(const float* att, int ldatt, const float* qk, const float* h, const float* dy,
+                                   float* dh, float* datt, float* dqk, int B, int HW, int C, hipStream_t stream) {
+  if (!att || !qk || !h || !dy || !dh || !datt || !dqk || B <= 0 || HW <= 0 || HW > 64 || (C & 3)) return ADM_EINVAL;
+  hipLaunchKernelGGL(spatial_att_bwd_kernel, dim3(B), dim3(256), 0, stream, att, ldatt, qk, h, dy, dh, datt, dqk, HW, C);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_q_sample(const float* x0, const float* noise, const float* t, float* xt, int B, long n, int schedule,
+                            hipStream_t stream) {
+  if (!x0 || !noise || !t || !xt || B <= 0 || n <= 0 || (schedule != 0 && schedule != 1)) return ADM_EINVAL;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid((long)B * n)), dim3(256), 0, stream, x0, noise, t, xt, B, n, schedule);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_ddm_loss(const float* c_pred, const float* n_pred, const float* x0, const float* noise,
+                            const float* w, float* per_sample, float* d_c, float* d_n, float gscale, int B, long n,
+                            hipStream_t stream) {
+  if (!c_pred || !n_pred || !x0 || !noise || !w || !per_sample || B <= 0 || n <= 0) return ADM_EINVAL;
+  if ((d_c == nullptr) != (d_n == nullptr)) return ADM_EINVAL;
+  if (hipMemsetAsync(per_sample, 0, sizeof(float) * B, stream) != hipSuccess) return ADM_ELAUNCH;
+  int chunks = (int)((n + 1023) / 1024);
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(ddm_loss_kernel, dim3(B, chunks), dim3(256), 0, stream, c_pred, n_pred, x0, noise, w, per_sample,
+                     d_c, d_n, gscale, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_sampler_step(double* x, const float* c_pred, const float* n_pred, double t_cur, double t_next,
+                                int schedule, int clip_x0, double scale_input, int last, long n, hipStream_t stream) {
+  if (!x || !c_pred || !n_pred || n <= 0 || (schedule != 0 && schedule != 1)) return ADM_EINVAL;
+  double gc = schedule == 0 ? sqrt(t_cur) : t_cur, gn = schedule == 0 ? sqrt(t_next) : t_next;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, c_pred, n_pred, t_cur, t_next, gc,
+                     gn, clip_x0, scale_input, last, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_sumsq(const float* g, double* sumsq, long n, hipStream_t stream) {
+  if (!g || !sumsq || n <= 0 || ((uintptr_t)g & 15)) return ADM_EINVAL;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n, 16)), dim3(256), 0, stream, g, sumsq, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_adamw_step(float* p, const float* g, float* m, float* v, float* ema, const double* sumsq, long n,
+                              float lr, float beta1, float beta2, float eps, float wd, float max_norm, int step,
+                              float ema_decay, float grad_scale, hipStream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return ADM_EINVAL;
+  float bc1 = 1.f - powf(beta1, (float)step);
+  float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, p, g, m, v, ema, sumsq, n, lr, beta1,
+                     beta2, eps, wd, max_norm, bc1, bc2s, 1.f - ema_decay, grad_scale);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}

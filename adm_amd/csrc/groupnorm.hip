@@ -1,0 +1,320 @@
+// GroupNorm (+ adaptive scale/shift) + SiLU (+ dropout), NHWC fp32, forward and backward.
+//
+// Replaces F.group_norm / silu / addcmul / F.dropout of UNetBlock.forward
+// (/root/reference/unet/uncond_unet.py:128, 191, 196, 200).  These kernels are HBM-bound: every
+// tensor is touched with 16-byte coalesced accesses, each thread keeps ONE channel quad (so all
+// per-channel coefficients live in registers) and walks rows with a fixed stride.
+//
+// Thread map (all kernels): C4 = C/4 float4 columns; block = C4 * R threads with R = 256 / C4 rows
+// in flight (>=1); thread (cq = tid % C4, ry = tid / C4) visits rows hw0 + ry, + R, ...
+#include "common.h"
+#include "../../include/adm_hip.h"
+
+namespace {
+
+__host__ __device__ inline int gn_rows_par(int C) { int r = 256 / (C / 4); return r < 1 ? 1 : r; }
+
+// ---------------------------------------------------------------- forward: moments
+__global__ void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int HW, int C, int G,
+                                  int rows_per_split) {
+  extern __shared__ float sm[];          // [R][C][2]
+  const int C4 = C >> 2, R = blockDim.x / C4;
+  const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
+  const int b = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int hw0 = s * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
+  const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  for (int hw = hw0 + ry; hw < hw1; hw += R) {
+    f32x4 v = xb[(long)hw * C4 + cq];
+    s1 += v;
+    s2 += v * v;
+  }
+  float* p1 = sm + (ry * C + cq * 4) * 2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { p1[2 * k] = s1[k]; p1[2 * k + 1] = s2[k]; }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double a = 0.0, q = 0.0;
+    for (int r = 0; r < R; ++r)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        a += (double)sm[(r * C + c) * 2];
+        q += (double)sm[(r * C + c) * 2 + 1];
+      }
+    double* o = ws + (((long)b * S + s) * G + g) * 2;
+    o[0] = a; o[1] = q;
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int BG, int G, int S,
+                                   double inv_n, float eps) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*G + g
+  if (i >= BG) return;
+  int b = i / G, g = i - b * G;
+  double a = 0.0, q = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const double* o = ws + (((long)b * S + s) * G + g) * 2;
+    a += o[0]; q += o[1];
+  }
+  double mean = a * inv_n;
+  double var = q * inv_n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---------------------------------------------------------------- forward: apply
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ ss, long ss_bstride, float* __restrict__ y, int HW, int C,
+                                int G, int rows_per_split, int silu, float drop_p, uint64_t seed) {
+  const int C4 = C >> 2, R = blockDim.x / C4;
+  const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
+  const int b = blockIdx.x;
+  const int hw0 = blockIdx.y * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
+  const int cpg = C / G;
+  f32x4 ca, cb;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int c = cq * 4 + k, g = c / cpg;
+    float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    float sc1 = 1.f, sh = 0.f;
+    if (ss) { sc1 = 1.f + ss[b * ss_bstride + c]; sh = ss[b * ss_bstride + C + c]; }
+    float ga = gamma[c] * rstd;
+    ca[k] = ga * sc1;
+    cb[k] = (beta[c] - mean * ga) * sc1 + sh;
+  }
+  const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
+  f32x4* yb = reinterpret_cast<f32x4*>(y + (long)b * HW * C);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int hw = hw0 + ry; hw < hw1; hw += R) {
+    f32x4 v = xb[(long)hw * C4 + cq];
+    f32x4 u = v * ca + cb;
+    if (silu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = silu_f(u[k]);
+    }
+    if (drop_p > 0.f) {
+      uint64_t e0 = ((uint64_t)b * HW + hw) * C + cq * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] *= dropout_keep_scale(seed, e0 + k, drop_p, inv_keep);
+    }
+    yb[(long)hw * C4 + cq] = u;
+  }
+}
+
+// ---------------------------------------------------------------- backward pass 1: per (b, split, c) partials
+__global__ void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ ss, long ss_bstride,
+                                      float* __restrict__ part, int HW, int C, int G, int rows_per_split, int silu,
+                                      float drop_p, uint64_t seed) {
+  extern __shared__ float sm[];          // [R][C][2]
+  const int C4 = C >> 2, R = blockDim.x / C4;
+  const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
+  const int b = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int hw0 = s * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
+  const int cpg = C / G;
+  f32x4 ca, cb, cm, cr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int c = cq * 4 + k, g = c / cpg;
+    float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    float sc1 = 1.f, sh = 0.f;
+    if (ss) { sc1 = 1.f + ss[b * ss_bstride + c]; sh = ss[b * ss_bstride + C + c]; }
+    float ga = gamma[c] * rstd;
+    ca[k] = ga * sc1;
+    cb[k] = (beta[c] - mean * ga) * sc1 + sh;
+    cm[k] = mean; cr[k] = rstd;
+  }
+  const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
+  const f32x4* gb = reinterpret_cast<const f32x4*>(dy + (long)b * HW * C);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  f32x4 r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+  for (int hw = hw0 + ry; hw < hw1; hw += R) {
+    f32x4 v = xb[(long)hw * C4 + cq];
+    f32x4 d = gb[(long)hw * C4 + cq];
+    f32x4 u = v * ca + cb;
+    if (drop_p > 0.f) {
+      uint64_t e0 = ((uint64_t)b * HW + hw) * C + cq * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] *= dropout_keep_scale(seed, e0 + k, drop_p, inv_keep);
+    }
+    if (silu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] *= silu_grad_f(u[k]);
+    }
+    r1 += d;
+    r2 += d * ((v - cm) * cr);
+  }
+  float* p1 = sm + (ry * C + cq * 4) * 2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { p1[2 * k] = r1[k]; p1[2 * k + 1] = r2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a += sm[r * C * 2 + i];
+    part[(((long)b * S + s) * C) * 2 + i] = a;
+  }
+}
+
+// pass 2: per b: totals over splits, d scale/shift, group means (m1, m2)
+__global__ void gn_bwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, const float* __restrict__ ss, long ss_bstride,
+                                     float* __restrict__ tot, float* __restrict__ gm, float* __restrict__ dss, int S,
+                                     int HW, int C, int G) {
+  extern __shared__ float sm[];          // [C][2] : gamma'(R1), gamma'(R2)
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float R1 = 0.f, R2 = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* q = part + (((long)b * S + s) * C + c) * 2;
+      R1 += q[0]; R2 += q[1];
+    }
+    tot[((long)b * C + c) * 2] = R1;
+    tot[((long)b * C + c) * 2 + 1] = R2;
+    float sc1 = ss ? 1.f + ss[b * ss_bstride + c] : 1.f;
+    float gp = gamma[c] * sc1;
+    sm[2 * c] = gp * R1;
+    sm[2 * c + 1] = gp * R2;
+    if (dss) {
+      dss[(long)b * 2 * C + c] = gamma[c] * R2 + beta[c] * R1;   // d/d scale: sum du * z,  z = xhat*gamma + beta
+      dss[(long)b * 2 * C + C + c] = R1;                          // d/d shift
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  const float inv_n = 1.f / ((float)HW * (float)cpg);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += sm[2 * c]; q += sm[2 * c + 1]; }
+    gm[((long)b * G + g) * 2] = a * inv_n;
+    gm[((long)b * G + g) * 2 + 1] = q * inv_n;
+  }
+}
+
+// pass 3: dgamma[c] += sum_b (1+s) R2, dbeta[c] += sum_b (1+s) R1   (deterministic order over b)
+__global__ void gn_bwd_param_kernel(const float* __restrict__ tot, const float* __restrict__ ss, long ss_bstride,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, q = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float sc1 = ss ? 1.f + ss[b * ss_bstride + c] : 1.f;
+    a += sc1 * tot[((long)b * C + c) * 2];
+    q += sc1 * tot[((long)b * C + c) * 2 + 1];
+  }
+  dbeta[c] += a;
+  dgamma[c] += q;
+}
+
+// pass 4: dx = rstd * (gamma' du - m1 - xhat m2)
+__global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                 const float* __restrict__ stats, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ ss, long ss_bstride,
+                                 const float* __restrict__ gm, float* __restrict__ dx, int HW, int C, int G,
+                                 int rows_per_split, int silu, float drop_p, uint64_t seed) {
+  const int C4 = C >> 2, R = blockDim.x / C4;
+  const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
+  const int b = blockIdx.x;
+  const int hw0 = blockIdx.y * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
+  const int cpg = C / G;
+  f32x4 ca, cb, cm, cr, cg, c1, c2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int c = cq * 4 + k, g = c / cpg;
+    float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    float sc1 = 1.f, sh = 0.f;
+    if (ss) { sc1 = 1.f + ss[b * ss_bstride + c]; sh = ss[b * ss_bstride + C + c]; }
+    float ga = gamma[c] * rstd;
+    ca[k] = ga * sc1;
+    cb[k] = (beta[c] - mean * ga) * sc1 + sh;
+    cm[k] = mean; cr[k] = rstd;
+    cg[k] = ga * sc1;                               // rstd * gamma'
+    c1[k] = rstd * gm[((long)b * G + g) * 2];       // rstd * m1
+    c2[k] = rstd * gm[((long)b * G + g) * 2 + 1];   // rstd * m2
+  }
+  const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
+  const f32x4* gb = reinterpret_cast<const f32x4*>(dy + (long)b * HW * C);
+  f32x4* ob = reinterpret_cast<f32x4*>(dx + (long)b * HW * C);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int hw = hw0 + ry; hw < hw1; hw += R) {
+    f32x4 v = xb[(long)hw * C4 + cq];
+    f32x4 d = gb[(long)hw * C4 + cq];
+    f32x4 u = v * ca + cb;
+    if (drop_p > 0.f) {
+      uint64_t e0 = ((uint64_t)b * HW + hw) * C + cq * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] *= dropout_keep_scale(seed, e0 + k, drop_p, inv_keep);
+    }
+    if (silu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] *= silu_grad_f(u[k]);
+    }
+    ob[(long)hw * C4 + cq] = cg * d - c1 - ((v - cm) * cr) * c2;
+  }
+}
+
+inline bool gn_shape_ok(int B, int HW, int C, int G) {
+  return B > 0 && HW > 0 && C > 0 && G > 0 && (C % 4) == 0 && (C % G) == 0 && C / 4 <= 1024;
+}
+inline int gn_threads(int C) { return (C / 4) * gn_rows_par(C); }
+
+}  // namespace
+
+extern "C" int adm_gn_splits(int HW, int C) {
+  (void)C;
+  int s = HW / 64;
+  if (s < 1) s = 1;
+  if (s > 16) s = 16;
+  return s;
+}
+
+extern "C" int adm_gn_stats(const float* x, float* stats, double* ws, int B, int HW, int C, int G, float eps,
+                            hipStream_t stream) {
+  if (!x || !stats || !ws || !gn_shape_ok(B, HW, C, G)) return ADM_EINVAL;
+  int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S), R = gn_rows_par(C);
+  size_t smem = (size_t)R * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(B, S), dim3(gn_threads(C)), smem, stream, x, ws, HW, C, G, rows);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(adm_cdiv(B * G, 256)), dim3(256), 0, stream, ws, stats, B * G, G, S,
+                     1.0 / ((double)HW * (C / G)), eps);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta,
+                            const float* ss, long ss_bstride, float* y, int B, int HW, int C, int G, int silu,
+                            float drop_p, uint64_t seed, hipStream_t stream) {
+  if (!x || !stats || !gamma || !beta || !y || !gn_shape_ok(B, HW, C, G) || drop_p < 0.f || drop_p >= 1.f)
+    return ADM_EINVAL;
+  int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(B, S), dim3(gn_threads(C)), 0, stream, x, stats, gamma, beta, ss,
+                     ss_bstride, y, HW, C, G, rows, silu, drop_p, seed);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+// red layout: part [B][S][C][2] | tot [B][C][2] | gm [B][G][2]   (floats)
+extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                          const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta,
+                          float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
+                          hipStream_t stream) {
+  if (!x || !dy || !stats || !gamma || !beta || !dx || !red || !gn_shape_ok(B, HW, C, G)) return ADM_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return ADM_EINVAL;
+  int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S), R = gn_rows_par(C);
+  float* part = red;
+  float* tot = part + (long)B * S * C * 2;
+  float* gm = tot + (long)B * C * 2;
+  size_t smem = (size_t)R * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(B, S), dim3(gn_threads(C)), smem, stream, x, dy, stats, gamma, beta,
+                     ss, ss_bstride, part, HW, C, G, rows, silu, drop_p, seed);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B), dim3(256), (size_t)C * 2 * sizeof(float), stream, part, gamma,
+                     beta, ss, ss_bstride, tot, gm, dss, S, HW, C, G);
+  if (dgamma)
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(adm_cdiv(C, 128)), dim3(128), 0, stream, tot, ss, ss_bstride, dgamma,
+                       dbeta, B, C);
+  hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(B, S), dim3(gn_threads(C)), 0, stream, x, dy, stats, gamma, beta, ss,
+                     ss_bstride, gm, dx, HW, C, G, rows, silu, drop_p, seed);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}

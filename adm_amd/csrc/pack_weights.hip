@@ -1,0 +1,151 @@
+// Weight / gradient layout transforms between the reference's parameter layout (OIHW,
+// /root/reference/unet/uncond_unet.py:85) and the K-contiguous packed operands of the implicit-GEMM
+// kernels.  Pure data movement over <= 11 MB per tensor; run once per optimiser step (or once per
+// model for sampling), so simplicity beats tuning here.
+#include "common.h"
+#include "../../include/adm_hip.h"
+
+namespace {
+
+// packed row (head, {q,k,v}, c) -> reference row (head, c, {q,k,v})   (uncond_unet.py:205)
+__device__ __forceinline__ int qkv_to_ref(int n) {
+  int h = n / 192, r = n - h * 192;
+  int j = r >> 6, c = r & 63;
+  return h * 192 + c * 3 + j;
+}
+__device__ __forceinline__ int qkv_to_packed(int n) {
+  int h = n / 192, r = n - h * 192;
+  int c = r / 3, j = r - c * 3;
+  return h * 192 + j * 64 + c;
+}
+
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int Ci, int taps,
+                                int Co_pad, int Ci_pad, int qkv) {
+  long total = (long)Co_pad * taps * Ci_pad;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int ci = idx % Ci_pad;
+    long t = idx / Ci_pad;
+    int tap = t % taps;
+    int cop = t / taps;
+    float v = 0.f;
+    if (cop < Co && ci < Ci) {
+      int co = qkv ? qkv_to_ref(cop) : cop;
+      v = w[((long)co * Ci + ci) * taps + tap];
+    }
+    out[idx] = v;
+  }
+}
+
+// out[ci][taps-1-tap][co_packed] = w[co][ci][tap]
+__global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int Ci, int taps,
+                                int Co_pad, int Ci_pad, int qkv) {
+  long total = (long)Ci_pad * taps * Co_pad;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int cop = idx % Co_pad;
+    long t = idx / Co_pad;
+    int tapf = t % taps;
+    int ci = t / taps;
+    float v = 0.f;
+    if (cop < Co && ci < Ci) {
+      int co = qkv ? qkv_to_ref(cop) : cop;
+      v = w[((long)co * Ci + ci) * taps + (taps - 1 - tapf)];
+    }
+    out[idx] = v;
+  }
+}
+
+__global__ void unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int taps,
+                              int Ci_pad, int qkv, int accumulate) {
+  long total = (long)Co * Ci * taps;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int tap = idx % taps;
+    long t = idx / taps;
+    int ci = t % Ci;
+    int co = t / Ci;
+    int cop = qkv ? qkv_to_packed(co) : co;
+    float v = dwp[((long)cop * taps + tap) * Ci_pad + ci];
+    dw[idx] = accumulate ? dw[idx] + v : v;
+  }
+}
+
+__global__ void permute_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int n_pad, int qkv,
+                                   int inverse) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  float v = 0.f;
+  if (i < n) {
+    int src = i;
+    if (qkv) src = inverse ? qkv_to_packed(i) : qkv_to_ref(i);
+    v = in[src];
+  }
+  out[i] = v;
+}
+
+// out[n] = sum_m a[m][n].  One block per 64-column strip x row-chunk; fp32 partials, atomics across chunks.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, float* __restrict__ out, int M,
+                                                     int N, int ld, int rows_per_block) {
+  __shared__ float part[4][64];
+  int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  int ry = threadIdx.x >> 6;
+  int m0 = blockIdx.y * rows_per_block;
+  int m1 = min(M, m0 + rows_per_block);
+  float s = 0.f;
+  if (col < N)
+    for (int m = m0 + ry; m < m1; m += 4) s += a[(long)m * ld + col];
+  part[ry][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) {
+    s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    atomicAdd(&out[col], s);
+  }
+}
+
+}  // namespace
+
+extern "C" int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci, int ks, int Co_pad,
+                               int Ci_pad, int qkv, hipStream_t stream) {
+  if (!w || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3) || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  if (qkv && (Co % 192 != 0 || Co_pad != Co)) return ADM_EINVAL;
+  int taps = ks * ks;
+  long total = (long)Co_pad * taps * Ci_pad;
+  int grid = (int)min((long)4096, (total + 255) / 256);
+  if (wp_fwd) hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid), dim3(256), 0, stream, w, wp_fwd, Co, Ci, taps, Co_pad, Ci_pad, qkv);
+  if (wp_bwd) hipLaunchKernelGGL(pack_bwd_kernel, dim3(grid), dim3(256), 0, stream, w, wp_bwd, Co, Ci, taps, Co_pad, Ci_pad, qkv);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
+                                int accumulate, hipStream_t stream) {
+  if (!dwp || !dw || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3) || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  if (qkv && (Co % 192 != 0)) return ADM_EINVAL;
+  int taps = ks * ks;
+  long total = (long)Co * Ci * taps;
+  int grid = (int)min((long)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(unpack_kernel, dim3(grid), dim3(256), 0, stream, dwp, dw, Co, Ci, taps, Ci_pad, qkv, accumulate);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_permute_vec(const float* in, float* out, int n, int n_pad, int qkv, int inverse,
+                               hipStream_t stream) {
+  if (!in || !out || n <= 0 || n_pad < n) return ADM_EINVAL;
+  if (qkv && n % 192 != 0) return ADM_EINVAL;
+  hipLaunchKernelGGL(permute_vec_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, stream, in, out, n, n_pad, qkv, inverse);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_colsum(const float* a, float* out, int M, int N, int ld, int accumulate, hipStream_t stream) {
+  if (!a || !out || M <= 0 || N <= 0 || ld < N) return ADM_EINVAL;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * N, stream) != hipSuccess) return ADM_ELAUNCH;
+  }
+  int strips = (N + 63) / 64;
+  int chunks = max(1, min(adm_cdiv(M, 64), 2048 / strips));
+  int rows = adm_cdiv(M, chunks);
+  chunks = adm_cdiv(M, rows);
+  hipLaunchKernelGGL(colsum_kernel, dim3(strips, chunks), dim3(256), 0, stream, a, out, M, N, ld, rows);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}

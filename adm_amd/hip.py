@@ -1,0 +1,96 @@
+"""ctypes binding of libadm_hip.so (the C ABI declared in include/adm_hip.h).
+
+There is NO fallback: if the shared library is missing or a kernel rejects its arguments the call
+raises.  PyTorch is used only for device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_double, c_float, c_int, c_long, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadm_hip.so")
+_lib = None
+
+P, I, L, F, D, U = c_void_p, c_int, c_long, c_float, c_double, c_uint64
+_SIGS = {
+    "adm_version": [],
+    "adm_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_pack_weight": [P, P, P, I, I, I, I, I, I, P],
+    "adm_unpack_wgrad": [P, P, I, I, I, I, I, I, I, P],
+    "adm_permute_vec": [P, P, I, I, I, I, P],
+    "adm_colsum": [P, P, I, I, I, I, P],
+    "adm_gn_splits": [I, I],
+    "adm_gn_stats": [P, P, P, I, I, I, I, F, P],
+    "adm_gn_apply": [P, P, P, P, P, L, P, I, I, I, I, I, F, U, P],
+    "adm_gn_bwd": [P, P, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, F, U, P],
+    "adm_attn_fwd": [P, P, P, I, I, I, P],
+    "adm_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
+    "adm_resample2x": [P, P, I, I, I, I, I, F, I, P],
+    "adm_nchw_to_nhwc": [P, I, P, L, P, I, I, I, I, P],
+    "adm_precond_out": [P, I, P, I, P, P, L, P, I, I, I, P],
+    "adm_precond_out_bwd": [P, P, L, P, I, I, I, I, P],
+    "adm_axpby_b": [P, I, P, P, P, L, P, I, L, P],
+    "adm_pos_embedding": [P, P, I, I, P],
+    "adm_silu_fwd": [P, P, L, P],
+    "adm_silu_bwd": [P, P, P, L, P],
+    "adm_add": [P, P, P, L, P],
+    "adm_copy_channels": [P, I, I, P, I, I, L, I, F, I, P],
+    "adm_spatial_att_fwd": [P, I, P, P, P, P, I, I, I, P],
+    "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, I, I, I, P],
+    "adm_q_sample": [P, P, P, P, I, L, I, P],
+    "adm_ddm_loss": [P, P, P, P, P, P, P, P, F, I, L, P],
+    "adm_sampler_step": [P, P, P, D, D, I, I, D, I, L, P],
+    "adm_sumsq": [P, P, L, P],
+    "adm_adamw_step": [P, P, P, P, P, P, L, F, F, F, F, F, F, I, F, F, P],
+}
+EXPORTS = tuple(_SIGS)
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libadm_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-8000:])
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise RuntimeError("building libadm_hip.so failed")
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no non-HIP fallback for the adm_amd hot path)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(_lib, name)      # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = args
+            fn.restype = c_int
+    return _lib
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> c_void_p:
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def call(name: str, *args):
+    rc = getattr(lib(), name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc} (-22 = unsupported shape/alignment, -5 = launch failure)")
+
+
+def require_cuda(t: torch.Tensor, what: str = "tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"adm_amd: {what} is on {t.device}; the HIP hot path needs a GPU tensor "
+                           "(no CPU fallback exists by design)")

@@ -1,0 +1,488 @@
+"""Autograd operators over the HIP C ABI (libadm_hip.so).
+
+Activations are NHWC fp32 CUDA tensors ``[B, H, W, C]`` (``[B, C]`` for the embedding path); the
+channel count of every GEMM-shaped operand is padded to a multiple of 32 (3 -> 32 at the stem and
+heads).  Parameters keep the reference's layouts (OIHW / [out, in]) so state_dicts interchange; the
+packed GEMM operands are derived tensors cached per parameter version.
+
+Each Function's backward is hand-written HIP as well -- autograd is only the tape.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Optional
+
+import torch
+
+from . import hip
+from .hip import call, ptr
+
+_f32 = torch.float32
+
+
+def ceil32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+def _new(shape, like: torch.Tensor, dtype=_f32) -> torch.Tensor:
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    hip.require_cuda(t, name)
+    if t.dtype != _f32:
+        raise RuntimeError(f"adm_amd: {name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# packed-weight cache
+# ------------------------------------------------------------------------------------------------
+class _Packed:
+    __slots__ = ("key", "fwd", "bwd", "bias")
+
+
+_pack_cache: dict = {}
+_pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
+
+
+def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: bool) -> _Packed:
+    """(wp_fwd, wp_bwd, bias_packed) for an OIHW / [out,in] parameter; re-packed only when the
+    parameter's version changed (in-place updates bump ``_version``; the fused optimiser, which writes
+    through raw pointers, calls invalidate_packed())."""
+    co, ci = weight.shape[0], weight.shape[1]
+    cop, cip = ceil32(co), ceil32(ci)
+    slot = (weight.data_ptr(), co, ci, ks, qkv)
+    key = (weight._version, _pack_epoch, None if bias is None else (bias.data_ptr(), bias._version))
+    ent = _pack_cache.get(slot)
+    if ent is not None and ent.key == key:
+        return ent
+    w = _chk(weight.detach(), "weight")
+    ent = _Packed()
+    ent.key = key
+    ent.fwd = _new((cop, ks * ks * cip), w)
+    ent.bwd = _new((cip, ks * ks * cop), w)
+    call("adm_pack_weight", ptr(w), ptr(ent.fwd), ptr(ent.bwd), co, ci, ks, cop, cip, int(qkv))
+    ent.bias = None
+    if bias is not None:
+        b = _chk(bias.detach(), "bias")
+        ent.bias = _new((cop,), w)
+        call("adm_permute_vec", ptr(b), ptr(ent.bias), co, cop, int(qkv), 0)
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[slot] = ent
+    return ent
+
+
+def invalidate_packed():
+    global _pack_epoch
+    _pack_epoch += 1
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution / linear
+# ------------------------------------------------------------------------------------------------
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, ks, up, qkv, tile):
+        x = _chk(x, "x")
+        B, H, W, cx = x.shape
+        co, ci = weight.shape[0], weight.shape[1]
+        cop, cip = ceil32(co), ceil32(ci)
+        if cx != cip:
+            raise RuntimeError(f"conv input has {cx} channels, expected {cip} (= ceil32({ci}))")
+        pk = packed(weight, bias, ks, qkv)
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        y = _new((B, Ho, Wo, cop), x)
+        res = None
+        if residual is not None:
+            res = _chk(residual, "residual")
+            if tuple(res.shape) != tuple(y.shape):
+                raise RuntimeError(f"residual shape {tuple(res.shape)} != output {tuple(y.shape)}")
+        call("adm_conv_fwd", ptr(x), ptr(pk.fwd), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop, cop,
+             cop, ks, int(up), tile)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.meta = (ks, up, qkv, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        ks, up, qkv, has_res = ctx.meta
+        dy = _chk(dy, "dy")
+        B, Ho, Wo, cop = dy.shape
+        co, ci = weight.shape[0], weight.shape[1]
+        cip = ceil32(ci)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            pk = packed(weight, bias, ks, qkv)
+            dxf = _new((B, Ho, Wo, cip), dy)
+            call("adm_conv_fwd", ptr(dy), ptr(pk.bwd), None, None, ptr(dxf), B, Ho, Wo, cop, cop, cip, cip, cip, cip,
+                 ks, 0, -1)
+            if up:   # gradient of nearest x2 = 2x2 sum
+                dx = _new((B, Ho // 2, Wo // 2, cip), dy)
+                call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)
+            else:
+                dx = dxf
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((cop, ks * ks * cip), device=dy.device, dtype=_f32)
+            call("adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+            dw = torch.empty_like(weight)
+            call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, int(qkv), 0)
+        if bias is not None and ctx.needs_input_grad[2]:
+            dbp = _new((cop,), dy)
+            call("adm_colsum", ptr(dy), ptr(dbp), B * Ho * Wo, cop, cop, 0)
+            db = _new((co,), dy)
+            call("adm_permute_vec", ptr(dbp), ptr(db), co, co, int(qkv), 1)
+        return dx, dw, db, (dy if has_res else None), None, None, None, None
+
+
+def conv2d(x, weight, bias=None, residual=None, *, up=False, qkv=False, tile=-1):
+    """NHWC conv: weight OIHW with k in {1,3}; optional fused nearest-x2 (``up``) and residual add."""
+    return _Conv.apply(x, weight, bias, residual, weight.shape[-1], bool(up), bool(qkv), tile)
+
+
+def linear(x, weight, bias=None, residual=None):
+    """x [B, in_pad] @ weight[out, in].T + bias (+ residual): the same implicit-GEMM kernel with H=W=1."""
+    B = x.shape[0]
+    r = None if residual is None else residual.reshape(B, 1, 1, -1)
+    y = _Conv.apply(x.reshape(B, 1, 1, -1), weight.reshape(weight.shape[0], weight.shape[1], 1, 1), bias, r, 1, False,
+                    False, -1)
+    return y.reshape(B, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm + scale/shift + SiLU + dropout
+# ------------------------------------------------------------------------------------------------
+_drop_counter = itertools.count(1)
+
+
+def next_dropout_seed() -> int:
+    return (torch.initial_seed() * 0x9E3779B1 + next(_drop_counter) * 0x85EBCA6B) & 0xFFFFFFFFFFFFFFFF
+
+
+class _GroupNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed):
+        x = _chk(x, "x")
+        B, H, W, C = x.shape
+        G = min(32, C // 4)
+        HW = H * W
+        g, b = _chk(gamma.detach(), "gamma"), _chk(beta.detach(), "beta")
+        S = hip.lib().adm_gn_splits(HW, C)
+        stats = _new((B, G, 2), x)
+        ws = _new((B * S * G * 2,), x, torch.float64)
+        call("adm_gn_stats", ptr(x), ptr(stats), ptr(ws), B, HW, C, G, 1e-5)
+        ssc, bstride = None, 0
+        if ss is not None:
+            ssc = _chk(ss, "scale_shift")
+            if ssc.shape[-1] != 2 * C or ssc.shape[0] not in (1, B):
+                raise RuntimeError(f"scale/shift shape {tuple(ssc.shape)} does not match C={C}, B={B}")
+            bstride = 0 if ssc.shape[0] == 1 else 2 * C
+        y = torch.empty_like(x)
+        call("adm_gn_apply", ptr(x), ptr(stats), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), B, HW, C, G, int(silu),
+             float(drop_p), seed)
+        ctx.save_for_backward(x, gamma, beta, ssc, stats)
+        ctx.meta = (G, S, bstride, silu, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, ss, stats = ctx.saved_tensors
+        G, S, bstride, silu, drop_p, seed = ctx.meta
+        dy = _chk(dy, "dy")
+        B, H, W, C = x.shape
+        HW = H * W
+        dx = torch.empty_like(x)
+        dss = None
+        if ss is not None and ctx.needs_input_grad[3]:
+            if bstride == 0 and B > 1:
+                raise RuntimeError("backward through a batch-broadcast scale/shift is not supported")
+            dss = _new((B, 2 * C), x)
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(beta)
+        red = _new((B * S * C * 2 + B * C * 2 + B * G * 2,), x)
+        call("adm_gn_bwd", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
+             ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
+        return dx, dgamma, dbeta, dss, None, None, None
+
+
+def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0):
+    return _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed))
+
+
+# ------------------------------------------------------------------------------------------------
+# attention core
+# ------------------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        qkv = _chk(qkv, "qkv")
+        B, H, W, C3 = qkv.shape
+        L = H * W
+        if C3 != heads * 192:
+            raise RuntimeError(f"qkv has {C3} channels, expected {heads * 192}")
+        out = _new((B, H, W, heads * 64), qkv)
+        lse = _new((B * heads, L), qkv)
+        call("adm_attn_fwd", ptr(qkv), ptr(out), ptr(lse), B, L, heads)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        dout = _chk(dout, "dout")
+        B, H, W, _ = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)
+        return dqkv, None
+
+
+def attention(qkv, heads: int):
+    return _Attention.apply(qkv, heads)
+
+
+# ------------------------------------------------------------------------------------------------
+# resampling, concat, activation
+# ------------------------------------------------------------------------------------------------
+class _Resample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = _chk(x, "x")
+        B, H, W, C = x.shape
+        y = _new((B, H // 2, W // 2, C) if mode == 0 else (B, 2 * H, 2 * W, C), x)
+        call("adm_resample2x", ptr(x), ptr(y), B, H, W, C, mode, 0.25 if mode == 0 else 1.0, 0)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        B, H, W, C = dy.shape
+        if ctx.mode == 0:      # d(mean 2x2) = up * .25
+            dx = _new((B, 2 * H, 2 * W, C), dy)
+            call("adm_resample2x", ptr(dy), ptr(dx), B, H, W, C, 1, 0.25, 0)
+        else:                  # d(nearest x2) = 2x2 sum
+            dx = _new((B, H // 2, W // 2, C), dy)
+            call("adm_resample2x", ptr(dy), ptr(dx), B, H, W, C, 0, 1.0, 0)
+        return dx, None
+
+
+def downsample2x(x):
+    return _Resample.apply(x, 0)
+
+
+def upsample2x(x):
+    return _Resample.apply(x, 1)
+
+
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, scale_b):
+        a, b = _chk(a, "a"), _chk(b, "b")
+        ca, cb = a.shape[-1], b.shape[-1]
+        M = a.numel() // ca
+        y = _new((*a.shape[:-1], ca + cb), a)
+        call("adm_copy_channels", ptr(a), ca, 0, ptr(y), ca + cb, 0, M, ca, 1.0, 0)
+        call("adm_copy_channels", ptr(b), cb, 0, ptr(y), ca + cb, ca, M, cb, float(scale_b), 0)
+        ctx.meta = (ca, cb, scale_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        ca, cb, scale_b = ctx.meta
+        M = dy.numel() // (ca + cb)
+        da = _new((*dy.shape[:-1], ca), dy)
+        db = _new((*dy.shape[:-1], cb), dy)
+        call("adm_copy_channels", ptr(dy), ca + cb, 0, ptr(da), ca, 0, M, ca, 1.0, 0)
+        call("adm_copy_channels", ptr(dy), ca + cb, ca, ptr(db), cb, 0, M, cb, float(scale_b), 0)
+        return da, db, None
+
+
+def concat_channels(a, b, scale_b: float = 1.0):
+    return _Concat.apply(a, b, scale_b)
+
+
+class _Silu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "x")
+        y = torch.empty_like(x)
+        call("adm_silu_fwd", ptr(x), ptr(y), x.numel())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        dx = torch.empty_like(x)
+        call("adm_silu_bwd", ptr(x), ptr(dy), ptr(dx), x.numel())
+        return dx
+
+
+def silu(x):
+    return _Silu.apply(x)
+
+
+def pos_embedding(t: torch.Tensor, channels: int) -> torch.Tensor:
+    t = _chk(t.reshape(-1), "noise_labels")
+    emb = _new((t.shape[0], channels), t)
+    call("adm_pos_embedding", ptr(t), ptr(emb), t.shape[0], channels)
+    return emb
+
+
+# ------------------------------------------------------------------------------------------------
+# SpatialAtt gate (+ the decouple residual)
+# ------------------------------------------------------------------------------------------------
+class _SpatialAtt(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att, qk, h, xres):
+        att, qk, h, xres = _chk(att, "att"), _chk(qk, "qk"), _chk(h, "h"), _chk(xres, "xres")
+        B, H, W, C = h.shape
+        y = torch.empty_like(h)
+        call("adm_spatial_att_fwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(xres), ptr(y), B, H * W, C)
+        ctx.save_for_backward(att, qk, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        att, qk, h = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        B, H, W, C = h.shape
+        dh = torch.empty_like(h)
+        datt = torch.empty_like(att)
+        dqk = torch.zeros_like(qk)
+        call("adm_spatial_att_bwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(dy), ptr(dh), ptr(datt), ptr(dqk), B,
+             H * W, C)
+        return datt, dqk, dh, dy
+
+
+def spatial_att_gate(att, qk, h, xres):
+    """softsign(softmax-pooled att) * h + xres; att = `map` conv output (channel 0 of a 32-padded tensor)."""
+    return _SpatialAtt.apply(att, qk, h, xres)
+
+
+# ------------------------------------------------------------------------------------------------
+# layout + preconditioning
+# ------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x: torch.Tensor, mul: Optional[torch.Tensor], cpad: int) -> torch.Tensor:
+    """[B,C,H,W] fp32/fp64 -> [B,H,W,cpad] fp32 scaled per batch by ``mul`` ([B] or [1])."""
+    hip.require_cuda(x, "x")
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32)
+    x = x if x.is_contiguous() else x.contiguous()
+    B, C, H, W = x.shape
+    y = _new((B, H, W, cpad), x)
+    bs = 0 if (mul is None or mul.numel() == 1) else 1
+    call("adm_nchw_to_nhwc", ptr(x), int(x.dtype == torch.float64), ptr(mul), bs, ptr(y), B, C, H * W, cpad)
+    return y
+
+
+class _PrecondOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, x, a, s):
+        f = _chk(f, "F")
+        B, H, W, ldf = f.shape
+        C = x.shape[1]
+        out = _new((B, C, H, W), f)
+        cbs = 0 if a.numel() == 1 else 1
+        call("adm_precond_out", ptr(x), int(x.dtype == torch.float64), ptr(f), ldf, ptr(a), ptr(s), cbs, ptr(out), B, C,
+             H * W)
+        ctx.save_for_backward(s)
+        ctx.meta = (ldf, C, cbs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (s,) = ctx.saved_tensors
+        ldf, C, cbs = ctx.meta
+        dout = _chk(dout, "dout")
+        B, _, H, W = dout.shape
+        df = _new((B, H, W, ldf), dout)
+        call("adm_precond_out_bwd", ptr(dout), ptr(s), cbs, ptr(df), ldf, B, C, H * W)
+        return df, None, None, None
+
+
+def precond_out(f_nhwc, x_nchw, c_skip, c_out):
+    """D = c_skip * x + c_out * F, NHWC(F) -> NCHW(D)."""
+    return _PrecondOut.apply(f_nhwc, x_nchw, c_skip, c_out)
+
+
+class _AxpbyB(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, x, a, s):
+        y = _chk(y, "y")
+        B = y.shape[0]
+        n = y.numel() // B
+        out = torch.empty_like(y)
+        cbs = 0 if s.numel() == 1 else 1
+        call("adm_axpby_b", ptr(x), int(x.dtype == torch.float64), ptr(y), ptr(a), ptr(s), cbs, ptr(out), B, n)
+        ctx.save_for_backward(s)
+        ctx.cbs = cbs
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (s,) = ctx.saved_tensors
+        dout = _chk(dout, "dout")
+        B = dout.shape[0]
+        dy = torch.empty_like(dout)
+        call("adm_axpby_b", None, 0, ptr(dout), None, ptr(s), ctx.cbs, ptr(dy), B, dout.numel() // B)
+        return dy, None, None, None
+
+
+def axpby_batch(y, x, a, s):
+    """out = a[b] * x + s[b] * y (grad flows to y only)."""
+    return _AxpbyB.apply(y, x, a, s)
+
+
+# ------------------------------------------------------------------------------------------------
+# analytic schedule
+# ------------------------------------------------------------------------------------------------
+def q_sample(x0, noise, t, schedule: int):
+    x0, noise, t = _chk(x0, "x0"), _chk(noise, "noise"), _chk(t, "t")
+    B = x0.shape[0]
+    xt = torch.empty_like(x0)
+    call("adm_q_sample", ptr(x0), ptr(noise), ptr(t), ptr(xt), B, x0.numel() // B, schedule)
+    return xt
+
+
+class _DdmLoss(torch.autograd.Function):
+    """loss = sum_b [w1 SSE(C_pred, -x0) + w2 SSE(noise_pred, noise)] / B ; also returns per-sample terms."""
+
+    @staticmethod
+    def forward(ctx, c_pred, n_pred, x0, noise, w):
+        c_pred, n_pred = _chk(c_pred, "C_pred"), _chk(n_pred, "noise_pred")
+        B = c_pred.shape[0]
+        n = c_pred.numel() // B
+        per = _new((B,), c_pred)
+        dc, dn = torch.empty_like(c_pred), torch.empty_like(n_pred)
+        call("adm_ddm_loss", ptr(c_pred), ptr(n_pred), ptr(x0), ptr(noise), ptr(w), ptr(per), ptr(dc), ptr(dn), 1.0 / B,
+             B, n)
+        ctx.save_for_backward(dc, dn)
+        ctx.mark_non_differentiable(per)
+        return per.sum() / B, per
+
+    @staticmethod
+    def backward(ctx, gloss, _gper):
+        dc, dn = ctx.saved_tensors
+        return dc * gloss, dn * gloss, None, None, None
+
+
+def ddm_loss(c_pred, n_pred, x0, noise, w):
+    return _DdmLoss.apply(c_pred, n_pred, _chk(x0, "x0"), _chk(noise, "noise"), _chk(w, "weights"))
+
+
+def sampler_step(x64, c_pred, n_pred, t_cur: float, t_next: float, schedule: int, clip_x0: bool, scale_input: float,
+                 last: bool):
+    call("adm_sampler_step", ptr(x64), ptr(_chk(c_pred, "C")), ptr(_chk(n_pred, "noise")), float(t_cur), float(t_next),
+         schedule, int(clip_x0), float(scale_input), int(last), x64.numel())
+    return x64

@@ -1,0 +1,171 @@
+/* adm_hip.h -- C ABI of libadm_hip.so: the MI355X (gfx950) hot path of DDM's UNet + analytic schedule.
+ *
+ * The reference (zacz08/ADM, a DDM fork) has no FFI / plugin ABI: its hot path is PyTorch ATen calls
+ * made from Python modules.  This header therefore defines the boundary a
+ * maintainer binds instead of those ATen calls; each entry point cites the reference lines whose
+ * arithmetic it replaces (paths relative to /root/reference).  INTEGRATION.md shows the ctypes
+ * binding and the two-line change in the reference's modules.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated; activations are NHWC
+ *     ([B][H][W][C], C contiguous; "ld*" = floats between consecutive pixels, >= C)
+ *   - no allocation, no synchronisation, no host<->device copies inside any call: work is enqueued on
+ *     `stream` (a hipStream_t) and the call returns; graph-capture safe
+ *   - return 0 on success, -22 (EINVAL) for a shape/alignment the kernels do not support,
+ *     -5 if the launch itself failed.  Nothing falls back to another implementation.
+ *   - channel counts seen by the GEMM-shaped kernels are multiples of 32 (the host pads 3 -> 32 for
+ *     the stem / heads; packed weights carry the zero padding)
+ */
+#ifndef ADM_HIP_H
+#define ADM_HIP_H
+#include <stdint.h>
+/* identical to HIP's own typedef, so this header needs no HIP include (C11 allows the repeat) */
+typedef struct ihipStream_t* hipStream_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int adm_version(void);
+
+/* ---------------- convolution / Linear: fp32-MFMA implicit GEMM ------------------------------ */
+
+/* y[B,H,W,N] = conv_{ks x ks, pad ks/2}(x) + bias (+ res).   Replaces Conv2d.forward
+ * (unet/uncond_unet.py:91-113: F.conv2d, the up branch's conv_transpose2d-with-ones == nearest x2
+ * when up=1, bias add) and Linear.forward (:62-66, as ks=1,H=W=1).  x is [B,Hin,Win,ldx] with
+ * (Hin,Win) = (H,W) or (H/2,W/2) when up.  wp = adm_pack_weight output [wrows][ks*ks*Cin].
+ * res (optional) [B*H*W][ldr] is added in the epilogue (the block's residual / skip add, :201, :209).
+ * tile: -1 = heuristic, 0..3 force a tile shape (tests). */
+int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float* res, float* y,
+                 int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                 int ks, int up, int tile, hipStream_t stream);
+
+/* dwp[Cout][ks*ks][Cin] += sum_pixels dy[p][co] * x[p+tap][ci]  (atomic fp32 accumulation over
+ * `splits` pixel ranges; caller zero-fills dwp).  The weight-gradient of the conv above
+ * (autograd of F.conv2d in the reference).  Cout, Cin multiples of 32. */
+int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
+                   int Cout, int lddy, int ks, int up, int splits, hipStream_t stream);
+
+/* OIHW [Co][Ci][ks][ks] (the reference's parameter layout, uncond_unet.py:85) ->
+ *   wp_fwd [Co_pad][ks*ks][Ci_pad]            (B operand of adm_conv_fwd)
+ *   wp_bwd [Ci_pad][ks*ks flipped][Co_pad]    (B operand of adm_conv_fwd computing dL/dx)
+ * zero padded.  qkv != 0: rows are permuted from the reference's (head, c, {q,k,v}) interleave
+ * (uncond_unet.py:205) to (head, {q,k,v}, c) so q/k/v are contiguous 64-float runs.
+ * Either output may be NULL. */
+int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci, int ks, int Co_pad, int Ci_pad,
+                    int qkv, hipStream_t stream);
+/* inverse of the fwd packing for gradients: dw OIHW = (accumulate ? dw : 0) + dwp */
+int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
+                     int accumulate, hipStream_t stream);
+/* out[i] = in[perm(i)] over n_pad entries (zero beyond n); qkv permutation of bias vectors.
+ * inverse=1 maps packed order back to the reference order. */
+int adm_permute_vec(const float* in, float* out, int n, int n_pad, int qkv, int inverse, hipStream_t stream);
+/* out[n] (+)= sum_m a[m][n]: bias gradients. */
+int adm_colsum(const float* a, float* out, int M, int N, int ld, int accumulate, hipStream_t stream);
+
+/* ---------------- GroupNorm (+ adaptive scale/shift) + SiLU (+ dropout) ----------------------- */
+
+/* stats[b][g] = {mean, rstd} of x[b, :, g*cpg:(g+1)*cpg]; ws: scratch of B*splits*G*2 doubles
+ * (splits = adm_gn_splits(HW, C)).  F.group_norm's moments (uncond_unet.py:128). */
+int adm_gn_splits(int HW, int C);
+int adm_gn_stats(const float* x, float* stats, double* ws, int B, int HW, int C, int G, float eps, hipStream_t stream);
+/* y = act( (xhat*gamma + beta) * (1 + scale[b,c]) + shift[b,c] ) * dropmask
+ * xhat = (x - mean) * rstd.  ss = [.., 2C] rows of (scale | shift) or NULL (uncond_unet.py:191-196);
+ * ss_bstride = floats between batch rows (0 = broadcast one row: sampling runs the embedding at batch 1).
+ * silu: apply SiLU.  drop_p > 0: inverted dropout with the stateless mask (seed, element index)
+ * (uncond_unet.py:200). */
+int adm_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
+                 long ss_bstride, float* y, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
+                 hipStream_t stream);
+/* Backward of adm_gn_apply.  Pass 1 reduces per (b,c): r1 = sum du, r2 = sum du*xhat into red[B][C][2]
+ * (du = dy * mask * act'(u)); pass 2 writes dx and, when the pointers are non-NULL, dss[B][2C]
+ * (d scale | d shift), dgamma[C], dbeta[C] (accumulated: caller zero-fills dgamma/dbeta). */
+int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+               const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta, float* red,
+               int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);
+
+/* ---------------- self-attention core -------------------------------------------------------- */
+
+/* qkv [B][L][heads*192] packed (head, {q,k,v}, 64); out [B][L][heads*64].
+ * out = softmax_k(q.k / 8) v per (b, head): uncond_unet.py:205-208.  L <= 32 or a multiple of 32 up to 256. */
+int adm_attn_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, hipStream_t stream);
+/* lse [B*heads][L] = log-sum-exp per query saved by the forward (may be NULL there when no backward
+ * follows); delta [B*heads][L] scratch.  dqkv has the qkv layout.  Autograd of :205-208. */
+int adm_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
+                 int B, int L, int heads, hipStream_t stream);
+
+/* ---------------- resampling / layout / elementwise ------------------------------------------ */
+
+/* mode 0: y[B,H/2,W/2,C] = scale * sum_{2x2} x   (down: scale .25, uncond_unet.py:107-108;
+ *         also the backward of up with scale 1)
+ * mode 1: y[B,2H,2W,C]   = scale * x[y/2,x/2]    (up: uncond_unet.py:105-106; backward of down with .25)
+ * acc != 0: y += ... */
+int adm_resample2x(const float* x, float* y, int B, int H, int W, int C, int mode, float scale, int acc,
+                   hipStream_t stream);
+/* y[B,H,W,Cpad] = mul[b] * x_nchw (channels >= C zero); x is fp32 or fp64 (x_is_f64).
+ * EDMPrecond's `c_in * x` + .to(float32) (uncond_unet.py:616, 628) fused with NCHW->NHWC. */
+int adm_nchw_to_nhwc(const void* x, int x_is_f64, const float* mul, long mul_bstride, float* y, int B, int C, int HW,
+                     int Cpad, hipStream_t stream);
+/* out_nchw[b,c,p] = a[b] * x_nchw[b,c,p] + s[b] * f_nhwc[b,p,c]   (D = c_skip x + c_out F, :631-632) */
+int adm_precond_out(const void* x, int x_is_f64, const float* f, int ldf, const float* a, const float* s,
+                    long coef_bstride, float* out, int B, int C, int HW, hipStream_t stream);
+/* backward of the two above w.r.t. f:  df_nhwc[b,p,c<C] = s[b] * dout_nchw[b,c,p], zero for c >= C */
+int adm_precond_out_bwd(const float* dout, const float* s, long coef_bstride, float* df, int ldf, int B, int C,
+                        int HW, hipStream_t stream);
+/* emb[b][0:C/2] = cos(t[b] f_i), emb[b][C/2:] = sin(t[b] f_i), f_i = (1/10000)^(i/(C/2))
+ * (PositionalEmbedding, uncond_unet.py:224-230) */
+int adm_pos_embedding(const float* t, float* emb, int B, int C, hipStream_t stream);
+/* y = silu(x) ; dx = dy * silu'(x) */
+int adm_silu_fwd(const float* x, float* y, long n, hipStream_t stream);
+int adm_silu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t stream);
+/* y = a + b (n floats); y may alias a */
+int adm_add(const float* a, const float* b, float* y, long n, hipStream_t stream);
+/* dst[m][dst_off + c] (+)= scale * src[m][src_off + c], c < C: channel concat / slice copies
+ * (torch.cat, :571, :578; `scale` carries uncond_unet_sd_3's skip-tuning ratio) */
+int adm_copy_channels(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
+                      float scale, int acc, hipStream_t stream);
+/* out[b,i] = a[b] * x[b,i] + s[b] * y[b,i]  (x may be NULL -> s*y only; x fp32 or fp64): the
+ * single-decoder variants' D_y = (x - (sigma-1) D_x) / g(sigma)  (uncond_unet_sd.py:602) and its backward */
+int adm_axpby_b(const void* x, int x_is_f64, const float* y, const float* a, const float* s, long coef_bstride,
+                float* out, int B, long n, hipStream_t stream);
+
+/* SpatialAtt (uncond_unet.py:27-37) after the 384->1 `map` conv:  att [B][HW][ldatt] (channel 0),
+ * y[b,p,c] = softsign( sum_j softmax_j(q_p k_j) att_j ) * h[b,p,c] + xres[b,p,c]
+ * q = qw*att+qb, k = kw*att+kb; qk = {qw,qb,kw,kb} on device.  HW <= 64. */
+int adm_spatial_att_fwd(const float* att, int ldatt, const float* qk, const float* h, const float* xres, float* y,
+                        int B, int HW, int C, hipStream_t stream);
+/* dh, datt (channel 0 of [B][HW][ldatt], other channels zeroed), dqk[4] (accumulated) */
+int adm_spatial_att_bwd(const float* att, int ldatt, const float* qk, const float* h, const float* dy, float* dh,
+                        float* datt, float* dqk, int B, int HW, int C, hipStream_t stream);
+
+/* ---------------- analytic schedule (ddm/ddm_const.py, ddm/ddm_const_2.py) -------------------- */
+
+/* schedule 0 = 'const' (sqrt(t) noise gain), 1 = 'const_2' (t).
+ * x_t = x0 + C t + g(t) eps with C = -x0   (ddm_const.py:284-287 / ddm_const_2.py:173-176); NCHW, n per image */
+int adm_q_sample(const float* x0, const float* noise, const float* t, float* xt, int B, long n, int schedule,
+                 hipStream_t stream);
+/* Weighted SSE loss and its gradients (ddm_const.py:335-358 with ddm/loss.py MSE_Loss 'sum'):
+ * per_sample[b] = w1[b] sum (Cp+x0)^2 + w2[b] sum (Np-noise)^2 ; dCp = gscale*2 w1 (Cp + x0) ; dNp likewise.
+ * w = [B][2] weights precomputed on device. */
+int adm_ddm_loss(const float* c_pred, const float* n_pred, const float* x0, const float* noise, const float* w,
+                 float* per_sample, float* d_c, float* d_n, float gscale, int B, long n, hipStream_t stream);
+/* One deterministic sampler update in fp64 (ddm_const.py:450-455 / ddm_const_2.py:363-368):
+ * x0 = x - C t - eps g(t); [clamp]; x_next = x0 + C t' + eps g(t');  if last: clamp, /scale, (x+1)/2 */
+int adm_sampler_step(double* x, const float* c_pred, const float* n_pred, double t_cur, double t_next, int schedule,
+                     int clip_x0, double scale_input, int last, long n, hipStream_t stream);
+
+/* ---------------- optimiser (train_uncond_dpm.py:292-310, ddm/ema.py:158-188) ---------------- */
+
+/* sumsq[0] += sum g^2 */
+int adm_sumsq(const float* g, double* sumsq, long n, hipStream_t stream);
+/* AdamW step on flat buffers with the clip factor computed on device from sumsq[0]:
+ * g *= min(1, max_norm/(sqrt(sumsq)+1e-6)); decoupled weight decay; optional EMA lerp
+ * (ema += (1-decay)(p-ema)) fused into the same pass when ema != NULL. */
+int adm_adamw_step(float* p, const float* g, float* m, float* v, float* ema, const double* sumsq, long n, float lr,
+                   float beta1, float beta2, float eps, float wd, float max_norm, int step, float ema_decay,
+                   float grad_scale, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADM_HIP_H */

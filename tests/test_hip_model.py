@@ -1,0 +1,193 @@
+"""GPU parity tests, model level: the HIP UNet / DDPM (through the reference-shaped Python API) against
+(a) the committed golden vectors the imported reference produced and (b) the CPU oracle on the same
+inputs.  rtol 1e-3 / atol 1e-4 fp32 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddm_ref, fill, unet_ref
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(model_channels=64, num_blocks=1, dropout=0.0)
+RTOL, ATOL = 1e-3, 1e-4
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+def close(got, want, scale=None, rtol=RTOL, atol=ATOL):
+    got = got.detach().cpu().double()
+    want = torch.as_tensor(np.asarray(want)).double()
+    s = max(float(want.abs().max()) if scale is None else scale, 1e-12)
+    torch.testing.assert_close(got / s, want / s, rtol=rtol, atol=atol)
+
+
+def build_unet(variant, gpu, full=False, **over):
+    import importlib
+    mod = importlib.import_module("unet." + variant)          # the reference's dotted path (alias package)
+    cfg = unet_ref.default_cfg(variant=variant, **({} if full else SMALL))
+    cfg.update(over)
+    kw = {k: cfg[k] for k in ("model_channels", "channel_mult", "channel_mult_emb", "num_blocks", "attn_resolutions",
+                              "dropout", "augment_dim")}
+    m = mod.EDMPrecond(img_resolution=32, img_channels=3, model_type="DhariwalUNet", **kw)
+    sd = fill.filled_state_dict(unet_ref.param_shapes(cfg))
+    m.load_state_dict(sd, strict=True)
+    return m.to(gpu), cfg, sd
+
+
+def small_inputs(cfg, B=2):
+    x = fill.hash_tensor((B, 3, 32, 32), "x", 1.0)
+    sigma = torch.tensor([0.05, 0.7, 0.31, 0.999][:B])
+    aug = fill.hash_tensor((B, cfg["augment_dim"]), "xaug", 1.0)
+    return x, sigma, aug
+
+
+@pytest.mark.parametrize("variant", unet_ref.VARIANTS)
+@pytest.mark.parametrize("use_aug", [0, 1])
+def test_precond_small_vs_golden(gpu, golden_dir, variant, use_aug):
+    g = np.load(os.path.join(golden_dir, "g5_precond_small.npz"))
+    m, cfg, _ = build_unet(variant, gpu)
+    m.eval()
+    x, sigma, aug = small_inputs(cfg)
+    kw = dict(augment_labels=aug.to(gpu)) if use_aug else {}
+    dx, dy = m(x.to(gpu), sigma.to(gpu), **kw)
+    p = f"{variant}.aug{use_aug}."
+    assert dx.dtype == torch.float32 and dx.shape == (2, 3, 32, 32)
+    close(dx, g[p + "D_x"]); close(dy, g[p + "D_y"])
+    gx, gy = fill.hash_tensor(dx.shape, "gx", 1.0).to(gpu), fill.hash_tensor(dy.shape, "gy", 1.0).to(gpu)
+    ((dx * gx).sum() + (dy * gy).sum()).backward()
+    named = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith(p + "grad."):
+            name = key[len(p + "grad."):]
+            got = named[name].grad.reshape(-1)[:4096]
+            close(got, g[key], scale=float(g[p + "gradnorm." + name]) / max(1.0, np.sqrt(min(got.numel(), 4096)) / 8))
+            gn = float(named[name].grad.double().norm())
+            assert abs(gn - float(g[p + "gradnorm." + name])) <= 2e-3 * float(g[p + "gradnorm." + name]) + 1e-6, name
+
+
+def test_every_parameter_gets_the_oracle_gradient(gpu):
+    """All 400+ parameter gradients of the reduced two-decoder model vs autograd through the CPU oracle."""
+    m, cfg, sd = build_unet("uncond_unet", gpu)
+    m.eval()
+    x, sigma, aug = small_inputs(cfg)
+    dx, dy = m(x.to(gpu), sigma.to(gpu), augment_labels=aug.to(gpu))
+    gx, gy = fill.hash_tensor(dx.shape, "gx", 1.0), fill.hash_tensor(dy.shape, "gy", 1.0)
+    ((dx * gx.to(gpu)).sum() + (dy * gy.to(gpu)).sum()).backward()
+    sdo = {k: v.clone().requires_grad_("resample" not in k) for k, v in sd.items()}
+    ox, oy = unet_ref.edm_precond(sdo, cfg, x, sigma, augment_labels=aug)
+    close(dx, ox); close(dy, oy)
+    ((ox * gx).sum() + (oy * gy).sum()).backward()
+    bad = []
+    for name, p in m.named_parameters():
+        want = sdo[name].grad
+        assert p.grad is not None, name
+        err = float((p.grad.cpu().double() - want.double()).norm() / (want.double().norm() + 1e-12))
+        if err > 2e-3:
+            bad.append((name, err))
+    assert not bad, bad[:10]
+
+
+def test_scalar_fp64_sigma_and_fp64_input(gpu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5b_scalar_sigma.npz"))
+    m, cfg, _ = build_unet("uncond_unet", gpu)
+    m.eval()
+    x, _, _ = small_inputs(cfg)
+    with torch.no_grad():
+        dx, dy = m(x.double().to(gpu), torch.tensor(0.37, dtype=torch.float64, device=gpu))
+    assert dx.dtype == torch.float32
+    close(dx, g["D_x"]); close(dy, g["D_y"])
+
+
+def test_full_width_cifar_model_vs_golden(gpu, golden_dir):
+    """The 216 M-parameter CIFAR-10 configuration (BASELINE configs[1] network), B=1."""
+    g = np.load(os.path.join(golden_dir, "g5c_full_width.npz"))
+    m, cfg, _ = build_unet("uncond_unet", gpu, full=True, dropout=0.0)
+    assert sum(p.numel() for p in m.parameters()) == 216141136
+    m.eval()
+    x = fill.hash_tensor((1, 3, 32, 32), "x", 1.0)
+    sigma = torch.tensor([0.05])
+    aug = fill.hash_tensor((1, 9), "xaug", 1.0)
+    with torch.no_grad():
+        dx, dy = m(x.to(gpu), sigma.to(gpu), augment_labels=aug.to(gpu))
+    close(dx, g["D_x"]); close(dy, g["D_y"])
+
+
+def make_ddpm(sched, gpu):
+    import importlib
+    variant, eps, smin = ("uncond_unet", 1e-4, 0.01) if sched == "const" else ("uncond_unet_sd_2", 1e-3, 0.001)
+    m, cfg, sd = build_unet(variant, gpu)
+    D = importlib.import_module("ddm.ddm_" + sched).DDPM
+    mcfg = dict(eps=eps, sigma_max=1, sigma_min=smin, weighting_loss=True, use_augment=False)
+    dpm = D(model=m, image_size=[32, 32], sampling_timesteps=10, loss_type="l2", start_dist="normal",
+            perceptual_weight=0.0, use_l1=False, cfg=mcfg, **mcfg).to(gpu)
+    return dpm, cfg, sd, eps, smin
+
+
+@pytest.mark.parametrize("sched", ["const", "const_2"])
+def test_training_step_vs_golden(gpu, golden_dir, sched):
+    g6 = np.load(os.path.join(golden_dir, "g6_training_step.npz"))
+    dpm, cfg, sd, eps, smin = make_ddpm(sched, gpu)
+    dpm.eval()      # dropout is 0 in this config anyway
+    x0 = fill.hash_tensor((2, 3, 32, 32), "x0", 1.0)
+    noise = fill.hash_tensor((2, 3, 32, 32), "noise", 1.7)
+    t = torch.tensor([0.23, 0.81])
+    loss, log = dpm.training_step({"image": x0.to(gpu)}, t=t.to(gpu), noise=noise.to(gpu))
+    close(loss, g6[sched + ".loss"]); close(log["train/loss_simple"], g6[sched + ".loss_simple"])
+    assert set(log) == {"train/loss_simple", "train/loss_vlb", "train/loss"}
+    loss.backward()
+    grads = [p.grad for p in dpm.parameters() if p.grad is not None]
+    gn = torch.sqrt(sum(gr.double().pow(2).sum() for gr in grads))
+    close(gn, g6[sched + ".grad_norm"])
+    close(dict(dpm.named_parameters())["model.model.map_layer1.bias"].grad, g6[sched + ".grad.map_layer1.bias"],
+          scale=float(g6[sched + ".grad_norm"]) / 8)
+    if sched == "const":
+        close(dpm.q_sample(x0.to(gpu), noise.to(gpu), t.to(gpu)), g6["const.x_noisy"])
+
+
+@pytest.mark.parametrize("sched", ["const", "const_2"])
+def test_deterministic_sampler_vs_golden(gpu, golden_dir, sched):
+    g7 = np.load(os.path.join(golden_dir, "g7_samplers.npz"))
+    dpm, cfg, sd, eps, smin = make_ddpm(sched, gpu)
+    dpm.eval()
+    xT = fill.hash_tensor((2, 3, 32, 32), "xT", 1.7, torch.float64)
+    img, traj = dpm.sample_fn_d((2, 3, 32, 32), x_T=xT.to(gpu), return_traj=True)
+    assert img.dtype == torch.float64 and float(img.min()) >= 0 and float(img.max()) <= 1
+    close(traj[2], g7[sched + ".x_after_step3"])
+    close(img, g7[sched + ".img"])
+    close(dpm.t_steps(), g7[sched + ".t_steps"], rtol=1e-12, atol=0)
+    img2 = dpm.sample(batch_size=2, x_T=xT.to(gpu))
+    assert torch.equal(img, img2)
+    if sched == "const_2":
+        draws = [fill.hash_tensor((2, 3, 32, 32), f"s{k}", 1.7, torch.float64) for k in range(11)]
+        simg = dpm.sample_fn_s((2, 3, 32, 32), x_T=draws[0].to(gpu), epsilons=draws[1:])
+        close(simg, g7["const_2.stochastic_img"])
+
+
+def test_training_mode_dropout_runs_and_is_seeded(gpu):
+    m, cfg, _ = build_unet("uncond_unet", gpu, dropout=0.1)
+    m.train()
+    x, sigma, _ = small_inputs(cfg)
+    torch.manual_seed(7)
+    a = m(x.to(gpu), sigma.to(gpu))[0]
+    b = m(x.to(gpu), sigma.to(gpu))[0]
+    assert not torch.equal(a, b)            # fresh mask per call
+    m.eval()
+    c = m(x.to(gpu), sigma.to(gpu))[0]
+    d = m(x.to(gpu), sigma.to(gpu))[0]
+    assert torch.equal(c, d)
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: the product path must fail loudly off-GPU."""
+    from adm_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.silu(torch.zeros(4))

@@ -1,0 +1,3 @@
+"""Dotted-path alias so YAML `class_name: unet.uncond_unet_sd_2.EDMPrecond` resolves to the HIP implementation."""
+from adm_amd.unet.uncond_unet_sd_2 import *  # noqa: F401,F403
+from adm_amd.unet.uncond_unet_sd_2 import EDMPrecond  # noqa: F401
