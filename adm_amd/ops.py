@@ -19,6 +19,26 @@ from .hip import call, ptr
 
 _f32 = torch.float32
 
+# bench.py sets PROFILE = [] to collect (kind, algorithmic_flops, start_event, end_event) per launch of
+# the GEMM-shaped kernels; events are recorded on the current stream = the stream the kernels run on.
+PROFILE = None
+
+
+class _Prof:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+
 
 def ceil32(n: int) -> int:
     return (n + 31) // 32 * 32
@@ -42,19 +62,19 @@ class _Packed:
     __slots__ = ("key", "fwd", "bwd", "bias")
 
 
-_pack_cache: dict = {}
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
 
 
 def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: bool) -> _Packed:
-    """(wp_fwd, wp_bwd, bias_packed) for an OIHW / [out,in] parameter; re-packed only when the
-    parameter's version changed (in-place updates bump ``_version``; the fused optimiser, which writes
-    through raw pointers, calls invalidate_packed())."""
+    """(wp_fwd, wp_bwd, bias_packed) for an OIHW / [out,in] parameter.  The entry lives ON the
+    parameter object (so it dies with it -- no global table that a recycled device address could
+    alias) and is rebuilt when the parameter's storage or version changed (in-place updates bump
+    ``_version``; the fused optimiser, which writes through raw pointers, calls invalidate_packed())."""
     co, ci = weight.shape[0], weight.shape[1]
     cop, cip = ceil32(co), ceil32(ci)
-    slot = (weight.data_ptr(), co, ci, ks, qkv)
-    key = (weight._version, _pack_epoch, None if bias is None else (bias.data_ptr(), bias._version))
-    ent = _pack_cache.get(slot)
+    key = (weight.data_ptr(), weight._version, _pack_epoch, ks, qkv,
+           None if bias is None else (bias.data_ptr(), bias._version))
+    ent = getattr(weight, "_adm_packed", None)
     if ent is not None and ent.key == key:
         return ent
     w = _chk(weight.detach(), "weight")
@@ -68,19 +88,16 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
         b = _chk(bias.detach(), "bias")
         ent.bias = _new((cop,), w)
         call("adm_permute_vec", ptr(b), ptr(ent.bias), co, cop, int(qkv), 0)
-    if len(_pack_cache) > 4096:
-        _pack_cache.clear()
-    _pack_cache[slot] = ent
+    try:
+        weight._adm_packed = ent
+    except AttributeError:
+        pass
     return ent
 
 
 def invalidate_packed():
     global _pack_epoch
     _pack_epoch += 1
-
-
-def clear_pack_cache():
-    _pack_cache.clear()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -103,8 +120,9 @@ class _Conv(torch.autograd.Function):
             res = _chk(residual, "residual")
             if tuple(res.shape) != tuple(y.shape):
                 raise RuntimeError(f"residual shape {tuple(res.shape)} != output {tuple(y.shape)}")
-        call("adm_conv_fwd", ptr(x), ptr(pk.fwd), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop, cop,
-             cop, ks, int(up), tile)
+        with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks):
+            call("adm_conv_fwd", ptr(x), ptr(pk.fwd), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop,
+                 cop, cop, ks, int(up), tile)
         ctx.save_for_backward(x, weight, bias)
         ctx.meta = (ks, up, qkv, residual is not None)
         return y
@@ -121,8 +139,9 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             pk = packed(weight, bias, ks, qkv)
             dxf = _new((B, Ho, Wo, cip), dy)
-            call("adm_conv_fwd", ptr(dy), ptr(pk.bwd), None, None, ptr(dxf), B, Ho, Wo, cop, cop, cip, cip, cip, cip,
-                 ks, 0, -1)
+            with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks):
+                call("adm_conv_fwd", ptr(dy), ptr(pk.bwd), None, None, ptr(dxf), B, Ho, Wo, cop, cop, cip, cip, cip,
+                     cip, ks, 0, -1)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
                 call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)
@@ -130,7 +149,8 @@ class _Conv(torch.autograd.Function):
                 dx = dxf
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros((cop, ks * ks * cip), device=dy.device, dtype=_f32)
-            call("adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+            with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks):
+                call("adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
             dw = torch.empty_like(weight)
             call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, int(qkv), 0)
         if bias is not None and ctx.needs_input_grad[2]:
@@ -143,15 +163,14 @@ class _Conv(torch.autograd.Function):
 
 def conv2d(x, weight, bias=None, residual=None, *, up=False, qkv=False, tile=-1):
     """NHWC conv: weight OIHW with k in {1,3}; optional fused nearest-x2 (``up``) and residual add."""
-    return _Conv.apply(x, weight, bias, residual, weight.shape[-1], bool(up), bool(qkv), tile)
+    return _Conv.apply(x, weight, bias, residual, weight.shape[-1] if weight.dim() == 4 else 1, bool(up), bool(qkv), tile)
 
 
 def linear(x, weight, bias=None, residual=None):
     """x [B, in_pad] @ weight[out, in].T + bias (+ residual): the same implicit-GEMM kernel with H=W=1."""
     B = x.shape[0]
     r = None if residual is None else residual.reshape(B, 1, 1, -1)
-    y = _Conv.apply(x.reshape(B, 1, 1, -1), weight.reshape(weight.shape[0], weight.shape[1], 1, 1), bias, r, 1, False,
-                    False, -1)
+    y = _Conv.apply(x.reshape(B, 1, 1, -1), weight, bias, r, 1, False, False, -1)
     return y.reshape(B, -1)
 
 
@@ -228,7 +247,8 @@ class _Attention(torch.autograd.Function):
             raise RuntimeError(f"qkv has {C3} channels, expected {heads * 192}")
         out = _new((B, H, W, heads * 64), qkv)
         lse = _new((B * heads, L), qkv)
-        call("adm_attn_fwd", ptr(qkv), ptr(out), ptr(lse), B, L, heads)
+        with _Prof("attn", 4.0 * L * L * 64 * B * heads):
+            call("adm_attn_fwd", ptr(qkv), ptr(out), ptr(lse), B, L, heads)
         ctx.save_for_backward(qkv, out, lse)
         ctx.heads = heads
         return out
@@ -240,7 +260,8 @@ class _Attention(torch.autograd.Function):
         B, H, W, _ = qkv.shape
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)
+        with _Prof("attn", 10.0 * (H * W) ** 2 * 64 * B * ctx.heads):
+            call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)
         return dqkv, None
 
 

@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDM hot path on MI355X: train images/sec (+ 10-step sample images/sec).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+torch.distributed.run, one rank per GPU over RCCL.  One "step" = one optimizer step of the full
+CIFAR-10 recipe network (BASELINE.json configs[1]: uncond two-decoder UNet, 216 M params, fp32,
+128 images per GPU, ddm_const schedule, dropout 0.1): q_sample -> UNet forward -> weighted loss ->
+backward -> [bucketed gradient all-reduce] -> clip 1.0 + AdamW + EMA.  Weak scaling: per-GPU batch
+is fixed.  After the timed steps rank 0 also times `sample(batch_size=128)` (10 NFE), measures the
+implicit-GEMM kernel's average duration with HIP events (roofline object) and times the CPU oracle
+on a bounded sample (cpu_baseline object).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sample", action="store_true")
+    ap.add_argument("--profile-only", action="store_true", help="run warmup+steps only (for rocprofv3)")
+    ap.add_argument("--small", action="store_true", help="reduced-width model (debug only; result marked invalid)")
+    return ap.parse_args()
+
+
+def build_model(dev, small=False):
+    from adm_amd.ddm.ddm_const import DDPM
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    kw = dict(model_channels=192, channel_mult=[1, 2, 2, 2], channel_mult_emb=4, num_blocks=3, attn_resolutions=[16, 8],
+              dropout=0.1, label_dropout=0, augment_dim=9)
+    if small:
+        kw.update(model_channels=64, num_blocks=1)
+    torch.manual_seed(1234)
+    unet = EDMPrecond(img_resolution=32, img_channels=3, sigma_data=1.0, model_type="DhariwalUNet", **kw)
+    # the reference zero-initialises conv1 / proj (dead branches at step 0); give them the Dhariwal init
+    # so the benchmark exercises every kernel with non-trivial data, as a mid-training model would
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if (name.endswith("conv1.weight") or name.endswith("proj.weight")) and float(p.abs().max()) == 0:
+                fan_in = p[0].numel()
+                p.copy_((torch.rand_like(p) * 2 - 1) * (1.0 / fan_in) ** 0.5)
+    mcfg = dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True, use_augment=False, ldm=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dpm = DDPM(model=unet, image_size=[32, 32], sampling_timesteps=10, loss_type="l2", start_dist="normal",
+                   perceptual_weight=0.0, use_l1=False, cfg=mcfg)
+    return dpm.to(dev)
+
+
+def cpu_baseline(seconds_cap=60.0):
+    """Oracle (plain PyTorch CPU restatement, kind='port') on BASELINE configs[0]: full 216 M model,
+    bs=8, fp32: 1 warm-up + 2 timed train steps (fwd+bwd, loss_simple) and one 10-step sample(8)."""
+    from oracle import ddm_ref, fill, unet_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = unet_ref.default_cfg(variant="uncond_unet", dropout=0.1)
+    sd = fill.filled_state_dict(unet_ref.param_shapes(cfg))
+    sd = {k: v.requires_grad_("resample" not in k) for k, v in sd.items()}
+    o = ddm_ref.OracleDDPM(sd, cfg, "const", eps=1e-4, sigma_min=0.01, sigma_max=1.0)
+    o.training = True
+    g = torch.Generator().manual_seed(0)
+    batch = {"image": torch.rand(8, 3, 32, 32, generator=g) * 2 - 1}
+    t = torch.rand(8, generator=torch.Generator().manual_seed(1)) * (1 - 1e-4) + 1e-4
+    noise = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    times = []
+    for i in range(3):
+        t0 = time.time()
+        loss, _ = o.training_step(batch, t=t, noise=noise)
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        times.append(time.time() - t0)
+        if sum(times) > seconds_cap:
+            break
+    train_s = sum(times[1:]) / max(1, len(times) - 1) if len(times) > 1 else times[0]
+    o.training = False
+    t0 = time.time()
+    o.sample(batch_size=8, x_T=torch.randn(8, 3, 32, 32, dtype=torch.float64, generator=torch.Generator().manual_seed(3)))
+    sample_s = time.time() - t0
+    return {"value": round(8 / train_s, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (plain PyTorch CPU) on the full 216M-param model, bs=8 fp32: {len(times) - 1 or 1} timed "
+                      f"train steps (fwd+bwd) after 1 warm-up = {train_s:.2f} s/step; one 10-step sample(8) = {sample_s:.2f} s",
+            "sample_images_per_sec": round(8 / sample_s, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from adm_amd import hip, ops
+    from adm_amd.optim import BucketedGradReducer, FlatParams, FusedAdamWEMA, ema_decay_at, lr_lambda
+    hip.lib()
+
+    dpm = build_model(dev, args.small)
+    dpm.train()
+    flat = FlatParams(dpm)
+    if world > 1:   # identical start on every rank
+        dist.broadcast(flat.flat, src=0)
+    reducer = BucketedGradReducer(flat)
+    opt = FusedAdamWEMA(flat, lr=1e-4, weight_decay=1e-4, max_norm=1.0, ema=(rank == 0))
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    batches = [{"image": torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1} for _ in range(2)]
+
+    def train_step(it):
+        flat.zero_grad()
+        loss, _ = dpm.training_step(batches[it & 1])
+        loss.backward()
+        reducer.finish()
+        # EMA every 8th step as in the recipe (ema_update_every: 8); decay from the reference's warm-up law,
+        # evaluated late in training (step 400k) so the lerp is a real lerp, not the early-training copy
+        opt.step(lr=1e-4 * lr_lambda(400000 + it, 1e-4, 5e-6, 800000), grad_scale=1.0 / world,
+                 ema_decay=ema_decay_at(400000 + it) if (it % 8 == 0) else None)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        train_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = train_step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    if args.profile_only:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    final_loss = float(loss)
+
+    # ---- roofline of the dominant kernel: the fp32-MFMA implicit GEMM (fwd + dgrad launches) and wgrad ----
+    roof = None
+    sample_ips = None
+    if rank == 0:
+        ops.PROFILE = []
+        train_step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        by = {}
+        for kind, flops, e0, e1 in recs:
+            a = by.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += e0.elapsed_time(e1); a[2] += 1
+        fl, ms, n = by.get("igemm", [0.0, 1e-9, 0])
+        roof = {"kernel": "igemm_f32_kernel (conv/linear forward + data-gradient)", "bound": "mfma",
+                "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "ms_per_step_in_kernel": round(ms, 2)}
+        if "wgrad" in by:
+            fl2, ms2, n2 = by["wgrad"]
+            roof["wgrad"] = {"kernel": "wgrad_f32_kernel", "achieved": round(fl2 / ms2 / 1e9, 2),
+                             "frac": round(fl2 / ms2 / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": n2,
+                             "ms_per_step_in_kernel": round(ms2, 2)}
+        if "attn" in by:
+            fl3, ms3, n3 = by["attn"]
+            roof["attention"] = {"kernel": "attn_fwd/bwd kernels", "achieved": round(fl3 / ms3 / 1e9, 2),
+                                 "frac": round(fl3 / ms3 / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": n3,
+                                 "ms_per_step_in_kernel": round(ms3, 2)}
+    # ---- 10-step sampling, every rank samples its own batch, no collectives ----
+    if not args.no_sample:
+        dpm.eval()
+        dpm.sample(batch_size=min(B, 16))
+        barrier()
+        t0 = time.perf_counter()
+        img = dpm.sample(batch_size=B)
+        barrier()
+        st = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([st], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            st = float(tmax)
+        assert img.dtype == torch.float64 and img.shape == (B, 3, 32, 32)
+        sample_ips = world * B / st
+
+    if rank == 0:
+        out = {"metric": "train images/sec (CIFAR-10 32x32 uncond DDM UNet, 1 optimizer step/iter) + 10-step sample images/sec",
+               "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "sample_images_per_sec": None if sample_ips is None else round(sample_ips, 2),
+               "config": {"workload": "BASELINE configs[1]: CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), "
+                                      f"bs={B}/GPU fp32, ddm_const schedule, dropout 0.1, loss_simple (LPIPS term needs "
+                                      "unfetchable VGG16 weights), clip 1.0 + AdamW + EMA(every 8)",
+                          "global_batch": world * B, "image": "3x32x32", "sampling_timesteps": 10,
+                          "parallelism": f"dp{world}", "valid": not args.small},
+               "final_loss": round(final_loss, 4), "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ def test_every_parameter_gets_the_oracle_gradient(gpu):
     ((dx * gx.to(gpu)).sum() + (dy * gy.to(gpu)).sum()).backward()
     sdo = {k: v.clone().requires_grad_("resample" not in k) for k, v in sd.items()}
     ox, oy = unet_ref.edm_precond(sdo, cfg, x, sigma, augment_labels=aug)
-    close(dx, ox); close(dy, oy)
+    close(dx, ox.detach()); close(dy, oy.detach())
     ((ox * gx).sum() + (oy * gy).sum()).backward()
     bad = []
     for name, p in m.named_parameters():
