@@ -25,6 +25,22 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32-input MFMA peak
 
 
+def log(msg):
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+
+
+def host_cores():
+    """CPU share actually usable by this process (the GPU box exposes far more cores than its cgroup grants)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,8 +83,9 @@ def cpu_baseline(seconds_cap=60.0):
     """Oracle (plain PyTorch CPU restatement, kind='port') on BASELINE configs[0]: full 216 M model,
     bs=8, fp32: 1 warm-up + 2 timed train steps (fwd+bwd, loss_simple) and one 10-step sample(8)."""
     from oracle import ddm_ref, fill, unet_ref
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} threads")
     cfg = unet_ref.default_cfg(variant="uncond_unet", dropout=0.1)
     sd = fill.filled_state_dict(unet_ref.param_shapes(cfg))
     sd = {k: v.requires_grad_("resample" not in k) for k, v in sd.items()}
@@ -86,6 +103,7 @@ def cpu_baseline(seconds_cap=60.0):
         for v in sd.values():
             v.grad = None
         times.append(time.time() - t0)
+        log(f"cpu_baseline: train step {i} took {times[-1]:.2f}s")
         if sum(times) > seconds_cap:
             break
     train_s = sum(times[1:]) / max(1, len(times) - 1) if len(times) > 1 else times[0]
@@ -93,6 +111,7 @@ def cpu_baseline(seconds_cap=60.0):
     t0 = time.time()
     o.sample(batch_size=8, x_T=torch.randn(8, 3, 32, 32, dtype=torch.float64, generator=torch.Generator().manual_seed(3)))
     sample_s = time.time() - t0
+    log(f"cpu_baseline: sample(8) took {sample_s:.2f}s")
     return {"value": round(8 / train_s, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle (plain PyTorch CPU) on the full 216M-param model, bs=8 fp32: {len(times) - 1 or 1} timed "
                       f"train steps (fwd+bwd) after 1 warm-up = {train_s:.2f} s/step; one 10-step sample(8) = {sample_s:.2f} s",
@@ -142,9 +161,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("model built; warm-up")
     for i in range(args.warmup):
         train_step(i)
     barrier()
+    log("warm-up done; timing")
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = train_step(args.warmup + i)
@@ -159,8 +180,9 @@ def main():
             dist.destroy_process_group()
         return
     ms_per_step = dt / args.steps * 1e3
+    log(f"{args.steps} steps in {dt:.3f}s = {ms_per_step:.1f} ms/step")
     value = world * B * args.steps / dt
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # ---- roofline of the dominant kernel: the fp32-MFMA implicit GEMM (fwd + dgrad launches) and wgrad ----
     roof = None
@@ -170,6 +192,7 @@ def main():
         train_step(args.warmup + args.steps)
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
+        log(f"profiled step: {len(recs)} GEMM-shaped launches")
         by = {}
         for kind, flops, e0, e1 in recs:
             a = by.setdefault(kind, [0.0, 0.0, 0])
@@ -204,6 +227,7 @@ def main():
             st = float(tmax)
         assert img.dtype == torch.float64 and img.shape == (B, 3, 32, 32)
         sample_ips = world * B / st
+        log(f"sample({B}) took {st:.3f}s")
 
     if rank == 0:
         out = {"metric": "train images/sec (CIFAR-10 32x32 uncond DDM UNet, 1 optimizer step/iter) + 10-step sample images/sec",

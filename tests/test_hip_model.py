@@ -87,10 +87,12 @@ def test_every_parameter_gets_the_oracle_gradient(gpu):
     close(dx, ox.detach()); close(dy, oy.detach())
     ((ox * gx).sum() + (oy * gy).sum()).backward()
     bad = []
+    gmax = max(float(v.grad.double().norm()) for v in sdo.values() if v.grad is not None)
     for name, p in m.named_parameters():
         want = sdo[name].grad
         assert p.grad is not None, name
-        err = float((p.grad.cpu().double() - want.double()).norm() / (want.double().norm() + 1e-12))
+        # floor: k_conv.bias has an analytically ZERO gradient (softmax shift invariance), so only noise is left
+        err = float((p.grad.cpu().double() - want.double()).norm() / (want.double().norm() + 1e-6 * gmax))
         if err > 2e-3:
             bad.append((name, err))
     assert not bad, bad[:10]
