@@ -25,8 +25,8 @@ PROFILE = None
 
 
 class _Prof:
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, tag=""):
+        self.kind, self.flops, self.tag = kind, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -37,7 +37,7 @@ class _Prof:
     def __exit__(self, *a):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag))
 
 
 def ceil32(n: int) -> int:
@@ -120,7 +120,7 @@ class _Conv(torch.autograd.Function):
             res = _chk(residual, "residual")
             if tuple(res.shape) != tuple(y.shape):
                 raise RuntimeError(f"residual shape {tuple(res.shape)} != output {tuple(y.shape)}")
-        with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks):
+        with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"fwd M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
             call("adm_conv_fwd", ptr(x), ptr(pk.fwd), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop,
                  cop, cop, ks, int(up), tile)
         ctx.save_for_backward(x, weight, bias)
@@ -139,7 +139,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             pk = packed(weight, bias, ks, qkv)
             dxf = _new((B, Ho, Wo, cip), dy)
-            with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks):
+            with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"dgrad M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
                 call("adm_conv_fwd", ptr(dy), ptr(pk.bwd), None, None, ptr(dxf), B, Ho, Wo, cop, cop, cip, cip, cip,
                      cip, ks, 0, -1)
             if up:   # gradient of nearest x2 = 2x2 sum
@@ -149,7 +149,7 @@ class _Conv(torch.autograd.Function):
                 dx = dxf
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros((cop, ks * ks * cip), device=dy.device, dtype=_f32)
-            with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks):
+            with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"wgrad P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                 call("adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
             dw = torch.empty_like(weight)
             call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, int(qkv), 0)

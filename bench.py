@@ -194,9 +194,16 @@ def main():
         recs, ops.PROFILE = ops.PROFILE, None
         log(f"profiled step: {len(recs)} GEMM-shaped launches")
         by = {}
-        for kind, flops, e0, e1 in recs:
+        shapes = {}
+        for kind, flops, e0, e1, tag in recs:
+            ms_ = e0.elapsed_time(e1)
             a = by.setdefault(kind, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += e0.elapsed_time(e1); a[2] += 1
+            a[0] += flops; a[1] += ms_; a[2] += 1
+            sa = shapes.setdefault(tag, [0.0, 0.0, 0])
+            sa[0] += flops; sa[1] += ms_; sa[2] += 1
+        if os.environ.get("ADM_BENCH_SHAPES"):
+            for tag, (f_, m_, n_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                log(f"  {tag:44s} n={n_:3d} total={m_:8.2f} ms  {f_ / max(m_, 1e-9) / 1e9:7.1f} TFLOP/s")
         fl, ms, n = by.get("igemm", [0.0, 1e-9, 0])
         roof = {"kernel": "igemm_f32_kernel (conv/linear forward + data-gradient)", "bound": "mfma",
                 "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -1,0 +1,114 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/adm_hip.h declares; host logic
+(module/state_dict layout, schedules, dotted-path aliases) matches the oracle and golden vectors.
+No compute call is made here (no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddm_ref, unet_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = dict(model_channels=64, num_blocks=1, dropout=0.0)
+
+
+def test_library_exports_every_declared_symbol():
+    from adm_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+    lib = hip.lib()
+    header = open(os.path.join(ROOT, "include", "adm_hip.h")).read()
+    declared = sorted(set(re.findall(r"^int\s+(adm_\w+)\s*\(", header, flags=re.M)))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in adm_hip.h but not exported"
+    assert sorted(hip.EXPORTS) == declared, set(hip.EXPORTS) ^ set(declared)
+    assert lib.adm_version() >= 1
+    assert lib.adm_gn_splits(1024, 192) == 16 and lib.adm_gn_splits(16, 384) == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from adm_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/libadm_hip.so")
+    with pytest.raises(RuntimeError, match="no non-HIP fallback"):
+        hip.lib()
+
+
+def test_ops_refuse_cpu_tensors():
+    from adm_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.silu(torch.zeros(4))
+    with pytest.raises(RuntimeError):
+        ops.group_norm_act(torch.zeros(1, 2, 2, 32), torch.ones(32), torch.zeros(32))
+
+
+@pytest.mark.parametrize("variant", unet_ref.VARIANTS)
+def test_state_dict_layout_matches_reference_names(variant):
+    """Same keys, shapes (incl. the 18 resample_filter buffers) as the reference's EDMPrecond: the oracle's
+    param_shapes() was asserted equal to the imported reference's state_dict in tools/make_golden.py."""
+    from ddm.utils import construct_class_by_name
+    cfg = unet_ref.default_cfg(variant=variant, **SMALL)
+    m = construct_class_by_name(class_name=f"unet.{variant}.EDMPrecond", img_resolution=32, img_channels=3,
+                                model_type="DhariwalUNet", cfg={"ignored": 1},
+                                **{k: cfg[k] for k in ("model_channels", "channel_mult", "channel_mult_emb", "num_blocks",
+                                                       "attn_resolutions", "dropout", "augment_dim")})
+    want = unet_ref.param_shapes(cfg)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == {k: tuple(s) for k, s in want.items()}
+    assert m.channels == 3 and m.self_condition is None and m.img_resolution == 32
+    # reference init statistics: conv1 / proj / map_augment are zero, Dhariwal layers kaiming_uniform * sqrt(1/3)
+    sd = m.state_dict()
+    assert float(sd["model.enc.32x32_block0.conv1.weight"].abs().max()) == 0
+    assert float(sd["model.map_augment.weight"].abs().max()) == 0
+    w = sd["model.enc.32x32_block0.conv0.weight"]
+    assert abs(float(w.std()) - (1 / (3 * w[0].numel())) ** 0.5) < 0.15 * (1 / (3 * w[0].numel())) ** 0.5
+
+
+def test_full_width_parameter_count_on_meta_device():
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    with torch.device("meta"):
+        m = EDMPrecond(img_resolution=32, img_channels=3, model_channels=192, channel_mult=[1, 2, 2, 2],
+                       channel_mult_emb=4, num_blocks=3, attn_resolutions=[16, 8], dropout=0.1, augment_dim=9)
+    assert sum(p.numel() for p in m.parameters()) == 216141136
+    assert len(m.state_dict()) == 829
+
+
+def test_ddpm_wrapper_contract(golden_dir):
+    from ddm.utils import construct_class_by_name
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    cfg = unet_ref.default_cfg(**SMALL)
+    unet = EDMPrecond(img_resolution=32, img_channels=3, **{k: cfg[k] for k in ("model_channels", "channel_mult", "num_blocks",
+                                                                               "attn_resolutions", "dropout", "augment_dim")})
+    model_cfg = dict(class_name="ddm.ddm_const.DDPM", image_size=[32, 32], ckpt_path=None, ignore_keys=[], only_model=False,
+                     sampling_timesteps=10, loss_type="l2", start_dist="normal", perceptual_weight=0.0, eps=1e-4,
+                     sigma_max=1, sigma_min=0.01, ldm=False, weighting_loss=True, use_l1=False, use_augment=True,
+                     unet={"class_name": "unet.uncond_unet.EDMPrecond"})
+    dpm = construct_class_by_name(model=unet, cfg=dict(model_cfg), **model_cfg)     # train_uncond_dpm.py:44-46 pattern
+    assert dpm.image_size == [32, 32] and dpm.channels == 3 and dpm.sampling_timesteps == 10
+    assert "eps" in dict(dpm.named_buffers()) and abs(float(dpm.eps) - 1e-4) < 1e-9
+    assert list(dpm.state_dict().keys())[1].startswith("model.model.")
+    g7 = np.load(os.path.join(golden_dir, "g7_samplers.npz"))
+    np.testing.assert_allclose(dpm.t_steps().numpy(), g7["const.t_steps"], rtol=1e-12)
+    t = torch.tensor([0.23, 0.81])
+    w1, w2 = dpm.loss_weights(t)
+    o1, o2 = ddm_ref.loss_weights("const", t, 1e-4)
+    assert torch.equal(w1, o1) and torch.equal(w2, o2)
+    import copy
+    copy.deepcopy(dpm)                                       # EMA(model) deep-copies it (ddm/ema.py:77)
+    with pytest.raises(AssertionError):
+        construct_class_by_name(model=unet, class_name="ddm.ddm_const.DDPM", image_size=[32, 32], start_dist="cauchy")
+    d2 = construct_class_by_name(model=unet, class_name="ddm.ddm_const_2.DDPM", image_size=[32, 32], perceptual_weight=0.0,
+                                 cfg=dict(eps=1e-3, sigma_min=0.001, weighting_loss=True))
+    np.testing.assert_allclose(d2.t_steps().numpy(), g7["const_2.t_steps"], rtol=1e-12)
+
+
+def test_lr_and_ema_schedules(golden_dir):
+    from adm_amd.optim import ema_decay_at, lr_lambda
+    g9 = np.load(os.path.join(golden_dir, "g9_schedules.npz"))
+    for s, d in zip(g9["ema_steps"], g9["ema_decay"]):
+        assert abs(ema_decay_at(int(s)) - d) < 1e-12
+    for i, r in zip(g9["lr_its"], g9["lr_ratio"]):
+        assert abs(lr_lambda(int(i), 1e-4, 5e-6, 800000) - r) < 1e-12
