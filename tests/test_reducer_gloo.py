@@ -28,7 +28,7 @@ def _worker(rank, world, port, out_path):
     from adm_amd.optim import BucketedGradReducer, FlatParams
     m = _model()
     flat = FlatParams(m)
-    red = BucketedGradReducer(flat, bucket_bytes=8 * 1024)       # several buckets
+    red = BucketedGradReducer(flat, bucket_bytes=2 * 1024)       # several buckets
     assert len(red.buckets) >= 3
     assert sum(hi - lo for lo, hi, _ in red.buckets) == flat.numel
     torch.manual_seed(1)
