@@ -30,7 +30,7 @@ struct IgemmP {
 
 constexpr int LDSS = 36;   // floats per LDS row (32 + 4 pad)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool UP>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32);
   constexpr int AI = BM / 32, BI = BN / 32;
@@ -46,49 +46,88 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- loader state: each thread owns float4 column c4 of rows r0 + 32 i ----
+  // Per row: a base pointer at tap (0,0) and a 9-bit mask of the taps that fall inside the image, both
+  // computed once; per K-step only `mask >> tap`, one add and the load remain.  Out-of-image taps read a
+  // valid dummy address (the row's centre pixel) and are zeroed with a select: no divergent branches.
   const int c4 = tid & 7, r0 = tid >> 3;
-  int a_b[AI], a_oy[AI], a_ox[AI];
-  bool a_ok[AI];
+  const float* a_base[AI];
+  unsigned a_mask[AI];
+  const int pad = p.ks >> 1;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     int m = m0 + r0 + 32 * i;
-    a_ok[i] = m < p.M;
-    int mm = a_ok[i] ? m : 0;
-    a_ox[i] = mm % p.W;
+    bool ok = m < p.M;
+    int mm = ok ? m : 0;
+    int ox = mm % p.W;
     int t = mm / p.W;
-    a_oy[i] = t % p.H;
-    a_b[i] = t / p.H;
+    int oy = t % p.H;
+    int b = t / p.H;
+    unsigned mask = 0;
+    if (ok) {
+      if (p.ks == 3) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          int iy = oy + tp / 3 - 1, ix = ox + tp % 3 - 1;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << tp;
+        }
+      } else {
+        mask = 1u;
+      }
+    }
+    a_mask[i] = mask;
+    // pointer to input pixel (oy, ox) [or (oy/2, ox/2) for the fused nearest-x2], channel quad c4
+    int py = UP ? (oy >> 1) : oy, px = UP ? (ox >> 1) : ox;
+    a_base[i] = p.x + ((long)(b * p.Hin + py) * p.Win + px) * p.ldx + c4 * 4;
+    // for `up`, the tap offset depends on the parity of (oy, ox); keep those in the mask's high bits
+    if (UP) a_mask[i] |= ((unsigned)(oy & 1) << 16) | ((unsigned)(ox & 1) << 17);
   }
   const int cchunks = p.Cin >> 5;
   const int KT = p.ks * p.ks * cchunks;
-  const int pad = p.ks >> 1;
+  const float* b_base[BI];
+  bool b_ok[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    int n = n0 + r0 + 32 * i;
+    b_ok[i] = n < p.wrows;
+    b_base[i] = p.w + (long)(b_ok[i] ? n : 0) * p.K + c4 * 4;
+  }
 
   f32x4 ra[AI], rb[BI];
-  auto load_stage = [&](int s) {
-    int tap = s / cchunks, c0 = (s - tap * cchunks) << 5;
-    int dy = (p.ks == 3) ? tap / 3 - pad : 0, dx = (p.ks == 3) ? tap % 3 - pad : 0;
+  int ld_tap = 0, ld_cc = 0;       // (tap, channel chunk) of the NEXT stage to load: no division per stage
+  int st_tap = 0;                  // tap of the stage held in ra/rb (for the zero-padding select at store time)
+  // Loads are issued raw (always from a valid address); the out-of-image select is applied only when the
+  // registers are written to LDS, AFTER the MFMAs of the current stage, so the loads stay in flight.
+  auto load_stage = [&]() {
+    const int tap = ld_tap, c0 = ld_cc << 5;
+    int dy = 0, dx = 0;
+    if (p.ks == 3) { dy = tap / 3 - pad; dx = tap - (tap / 3) * 3 - pad; }
+    const long tap_off = ((long)dy * p.Win + dx) * p.ldx + c0;      // wave-uniform (non-up case)
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
-      bool v = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      if (p.up) { iy >>= 1; ix >>= 1; }
-      const float* ptr = p.x + ((long)(a_b[i] * p.Hin + iy) * p.Win + ix) * p.ldx + c0 + c4 * 4;
-      ra[i] = v ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool v = (a_mask[i] >> tap) & 1u;
+      long off = tap_off;
+      if (UP) {     // input pixel of output (oy+dy, ox+dx) is ((oy+dy)>>1, (ox+dx)>>1)
+        int py = (int)((a_mask[i] >> 16) & 1u), px = (int)((a_mask[i] >> 17) & 1u);
+        int qy = ((py + dy + 2) >> 1) - 1, qx = ((px + dx + 2) >> 1) - 1;     // floor((parity + d) / 2)
+        off = ((long)qy * p.Win + qx) * p.ldx + c0;
+      }
+      ra[i] = *reinterpret_cast<const f32x4*>(a_base[i] + (v ? off : (long)c0));
     }
+    const int koff = tap * p.Cin + c0;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      int n = n0 + r0 + 32 * i;
-      const float* ptr = p.w + (long)n * p.K + tap * p.Cin + c0 + c4 * 4;
-      rb[i] = (n < p.wrows) ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_base[i] + koff);
+    st_tap = tap;
+    if (++ld_cc == cchunks) { ld_cc = 0; ++ld_tap; }
   };
   auto store_stage = [&](int buf) {
     float* Ab = As + buf * BM * LDSS;
     float* Bb = Bs + buf * BN * LDSS;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&Ab[(r0 + 32 * i) * LDSS + c4 * 4]) = ra[i];
+    for (int i = 0; i < AI; ++i)
+      *reinterpret_cast<f32x4*>(&Ab[(r0 + 32 * i) * LDSS + c4 * 4]) = ((a_mask[i] >> st_tap) & 1u) ? ra[i] : zero;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bb[(r0 + 32 * i) * LDSS + c4 * 4]) = rb[i];
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bb[(r0 + 32 * i) * LDSS + c4 * 4]) = b_ok[i] ? rb[i] : zero;
   };
 
   f32x16 acc[MT][NT];
@@ -99,13 +138,13 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_stage(0);
+  load_stage();
   store_stage(0);
   __syncthreads();
 
   for (int s = 0; s < KT; ++s) {
     const int buf = s & 1;
-    if (s + 1 < KT) load_stage(s + 1);
+    if (s + 1 < KT) load_stage();
     const float* Ab = As + buf * BM * LDSS + (wm * MT * 32 + lr) * LDSS + lh * 4;
     const float* Bb = Bs + buf * BN * LDSS + (wn * NT * 32 + lr) * LDSS + lh * 4;
 #pragma unroll
@@ -128,6 +167,31 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5) ----
+  // Fast path for interior tiles: no per-element predicates, so the residual loads of a 32x32 block are
+  // issued together and waited for once (the predicated form serialises 64 dependent load->store pairs).
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  if (full) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + (wn * NT + j) * 32 + lr;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const long mb = m0 + (wm * MT + i) * 32 + 4 * lh;
+        float rv[16];
+        if (p.res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = p.res[(mb + (r & 3) + 8 * (r >> 2)) * p.ldr + n];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.y[(mb + (r & 3) + 8 * (r >> 2)) * p.ldy + n] = acc[i][j][r] + bv + rv[r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + (wn * NT + j) * 32 + lr;
@@ -149,21 +213,26 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_igemm(IgemmP p, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool UP>
+int launch_igemm_up(IgemmP p, hipStream_t st) {
   static bool attr_set = false;
   constexpr int smem = 2 * (BM + BN) * LDSS * (int)sizeof(float);
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<BM, BN, WM, WN>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<BM, BN, WM, WN, UP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   p.tilesN = adm_cdiv(p.N, BN);
   long grid = (long)adm_cdiv(p.M, BM) * p.tilesN;
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, UP>), dim3((unsigned)grid), dim3(256), smem, st, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(IgemmP p, hipStream_t st) {
+  return p.up ? launch_igemm_up<BM, BN, WM, WN, true>(p, st) : launch_igemm_up<BM, BN, WM, WN, false>(p, st);
 }
 
 }  // namespace
@@ -181,15 +250,21 @@ extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, 
   p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.K = ks * ks * Cin; p.ldy = ldy; p.ldr = ldr; p.ks = ks; p.up = up; p.wrows = wrows;
   p.tilesN = 0;
-  if (tile < 0) {  // heuristic: biggest tile that still gives >= ~1.5 waves of workgroups over 256 CUs
-    long m128 = adm_cdiv(p.M, 128), m64 = adm_cdiv(p.M, 64);
-    if (N % 128 == 0 && m128 * (N / 128) >= 384) tile = 0;
-    else if (N % 96 == 0 && m128 * (N / 96) >= 384) tile = 1;
-    else if (N <= 32) tile = 3;
-    else if (N % 128 == 0 && m128 * (N / 128) >= 200) tile = 0;
-    else if (N % 96 == 0 && m128 * (N / 96) >= 200) tile = 1;
-    else tile = 2;
-    (void)m64;
+  if (tile < 0) {
+    // Cost model: time ~ rounds * (work of one tile) / (per-tile efficiency), rounds = ceil(tiles / resident slots).
+    // Resident workgroups per CU follow from the LDS footprint (2 for the 128-row tiles, 4 for 64x64).
+    struct Cand { int id, bm, bn, per_cu; double eff; };
+    const Cand cands[4] = {{0, 128, 128, 2, 1.00}, {1, 128, 96, 2, 0.97}, {2, 64, 64, 4, 0.80}, {3, 128, 32, 4, 0.70}};
+    double best = 1e300;
+    for (const Cand& c : cands) {
+      long tiles = (long)adm_cdiv(p.M, c.bm) * adm_cdiv(N, c.bn);
+      long slots = 256L * c.per_cu;
+      long rounds = (tiles + slots - 1) / slots;
+      // measured: a workgroup alone on a CU takes as long as two sharing it (it cannot hide its own
+      // barrier stalls), so time goes by whole rounds of resident slots
+      double t = (double)rounds * c.bm * c.bn / c.eff;
+      if (t < best) { best = t; tile = c.id; }
+    }
   }
   switch (tile) {
     case 0: return launch_igemm<128, 128, 2, 2>(p, stream);

@@ -17,7 +17,7 @@ namespace {
 
 struct WgradP {
   const float* x; const float* dy; float* dwp;
-  int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic;
+  int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh;
 };
 
 template <int TM, int TN>
@@ -62,10 +62,18 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
       int pp = pb + b_r + i * BR;
       bool v = b_cok && pp < pend;
       int ppp = v ? pp : 0;
-      int ox = ppp % p.W;
-      int t = ppp / p.W;
-      int oy = t % p.H;
-      int b = t / p.H;
+      int ox, oy, b;
+      if (p.lw >= 0) {            // power-of-two image: shifts instead of integer division
+        ox = ppp & (p.W - 1);
+        int t = ppp >> p.lw;
+        oy = t & (p.H - 1);
+        b = t >> p.lh;
+      } else {
+        ox = ppp % p.W;
+        int t = ppp / p.W;
+        oy = t % p.H;
+        b = t / p.H;
+      }
       int iy = oy + dy_, ix = ox + dx_;
       v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       if (p.up) { iy >>= 1; ix >>= 1; }
@@ -153,12 +161,15 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
   p.x = x; p.dy = dy; p.dwp = dwp;
   p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.ks = ks; p.up = up; p.tilesN = 0;
+  auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  p.lw = ilog2(W); p.lh = ilog2(H);
+  if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
   const int TM = (Cout % 128 == 0) ? 128 : 64;
   const int TN = (Cin % 128 == 0) ? 128 : 64;
   if (splits <= 0) {   // aim for >= ~512 workgroups, keep >= 256 pixels per split
     long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
-    splits = (int)((512 + tiles - 1) / tiles);
-    int maxs = (p.P + 255) / 256;
+    splits = (int)((512 + tiles / 2) / tiles);      // ~one full round of 2 workgroups per CU
+    int maxs = (p.P + 511) / 512;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
   }

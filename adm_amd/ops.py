@@ -84,7 +84,9 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     ent.bwd = _new((cip, ks * ks * cop), w)
     call("adm_pack_weight", ptr(w), ptr(ent.fwd), ptr(ent.bwd), co, ci, ks, cop, cip, int(qkv))
     ent.bias = None
-    if bias is not None:
+    if bias is not None and not qkv and cop == co:
+        ent.bias = _chk(bias.detach(), "bias")          # usable as is
+    elif bias is not None:
         b = _chk(bias.detach(), "bias")
         ent.bias = _new((cop,), w)
         call("adm_permute_vec", ptr(b), ptr(ent.bias), co, cop, int(qkv), 0)
@@ -98,6 +100,26 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
 def invalidate_packed():
     global _pack_epoch
     _pack_epoch += 1
+
+
+# ------------------------------------------------------------------------------------------------
+# direct gradient accumulation
+# ------------------------------------------------------------------------------------------------
+# adm_amd.optim.FlatParams marks parameters whose .grad is a view into the flat gradient buffer
+# (``p._adm_direct = True``).  For those, the backward kernels accumulate straight into ``p.grad``
+# (saving a temporary, a zero-fill and autograd's ``grad += tmp`` pass per parameter) and return None
+# to autograd; ``p._adm_grad_sink`` (set by the bucketed reducer) is then called in place of the
+# post-accumulate-grad hook that autograd would have fired.
+def _direct_grad(param):
+    if param is not None and getattr(param, "_adm_direct", False) and param.grad is not None:
+        return param.grad
+    return None
+
+
+def _notify(param):
+    sink = getattr(param, "_adm_grad_sink", None)
+    if sink is not None:
+        sink(param)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -151,13 +173,27 @@ class _Conv(torch.autograd.Function):
             dwp = torch.zeros((cop, ks * ks * cip), device=dy.device, dtype=_f32)
             with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"wgrad P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                 call("adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
-            dw = torch.empty_like(weight)
-            call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, int(qkv), 0)
+            sink = _direct_grad(weight)
+            if sink is not None:
+                call("adm_unpack_wgrad", ptr(dwp), ptr(sink), co, ci, ks, cop, cip, int(qkv), 1)
+                _notify(weight)
+            else:
+                dw = torch.empty_like(weight)
+                call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, int(qkv), 0)
         if bias is not None and ctx.needs_input_grad[2]:
-            dbp = _new((cop,), dy)
-            call("adm_colsum", ptr(dy), ptr(dbp), B * Ho * Wo, cop, cop, 0)
-            db = _new((co,), dy)
-            call("adm_permute_vec", ptr(dbp), ptr(db), co, co, int(qkv), 1)
+            sink = _direct_grad(bias)
+            if not qkv and cop == co:
+                if sink is not None:
+                    call("adm_colsum", ptr(dy), ptr(sink), B * Ho * Wo, cop, cop, 1)
+                    _notify(bias)
+                else:
+                    db = _new((co,), dy)
+                    call("adm_colsum", ptr(dy), ptr(db), B * Ho * Wo, cop, cop, 0)
+            else:
+                dbp = _new((cop,), dy)
+                call("adm_colsum", ptr(dy), ptr(dbp), B * Ho * Wo, cop, cop, 0)
+                db = _new((co,), dy)
+                call("adm_permute_vec", ptr(dbp), ptr(db), co, co, int(qkv), 1)
         return dx, dw, db, (dy if has_res else None), None, None, None, None
 
 
@@ -222,11 +258,16 @@ class _GroupNormAct(torch.autograd.Function):
             if bstride == 0 and B > 1:
                 raise RuntimeError("backward through a batch-broadcast scale/shift is not supported")
             dss = _new((B, 2 * C), x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(beta)
+        sg, sb = _direct_grad(gamma), _direct_grad(beta)
+        direct = sg is not None and sb is not None
+        dgamma = sg if direct else torch.zeros_like(gamma)
+        dbeta = sb if direct else torch.zeros_like(beta)
         red = _new((B * S * C * 2 + B * C * 2 + B * G * 2,), x)
         call("adm_gn_bwd", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
              ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
+        if direct:
+            _notify(gamma); _notify(beta)
+            return dx, None, None, dss, None, None, None
         return dx, dgamma, dbeta, dss, None, None, None
 
 

@@ -43,6 +43,7 @@ class FlatParams:
             self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + p.numel()].view(p.shape)
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            p._adm_direct = True        # ops.* backward kernels may accumulate straight into p.grad
 
     def zero_grad(self):
         self.grad.zero_()
@@ -89,7 +90,9 @@ class BucketedGradReducer:
         self.handles = []
         if self.world > 1:
             for idx, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(idx))
+                hook = self._make_hook(idx)
+                p.register_post_accumulate_grad_hook(hook)     # gradients that arrive through autograd
+                p._adm_grad_sink = hook                         # gradients the HIP kernels accumulate directly
 
     def _make_hook(self, idx):
         def hook(_p):

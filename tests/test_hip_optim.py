@@ -1,0 +1,78 @@
+"""GPU: flat-buffer training state.  (1) gradients accumulated directly into the flat buffer by the HIP
+backward kernels equal the autograd-returned gradients; (2) the fused clip + AdamW + EMA kernel equals
+torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW + lerp (train_uncond_dpm.py:292-310, ddm/ema.py:186)."""
+import copy
+
+import pytest
+import torch
+
+from oracle import fill, unet_ref
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(model_channels=64, num_blocks=1, dropout=0.0)
+
+
+def _model(gpu):
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    cfg = unet_ref.default_cfg(variant="uncond_unet", **SMALL)
+    kw = {k: cfg[k] for k in ("model_channels", "channel_mult", "channel_mult_emb", "num_blocks", "attn_resolutions",
+                              "dropout", "augment_dim")}
+    m = EDMPrecond(img_resolution=32, img_channels=3, **kw)
+    m.load_state_dict(fill.filled_state_dict(unet_ref.param_shapes(cfg)))
+    return m.to(gpu).eval()
+
+
+def _loss(m, gpu):
+    x = fill.hash_tensor((2, 3, 32, 32), "x", 1.0).to(gpu)
+    sigma = torch.tensor([0.05, 0.7], device=gpu)
+    dx, dy = m(x, sigma)
+    return (dx * fill.hash_tensor(dx.shape, "gx", 1.0).to(gpu)).sum() + (dy * fill.hash_tensor(dy.shape, "gy", 1.0).to(gpu)).sum()
+
+
+def test_direct_flat_gradients_and_fused_adamw():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd.optim import FlatParams, FusedAdamWEMA
+    gpu = torch.device("cuda:0")
+    ref = _model(gpu)
+    _loss(ref, gpu).backward()                     # plain autograd path (no flat buffers)
+    m = _model(gpu)
+    flat = FlatParams(m)
+    for _ in range(2):                             # second pass: zero_grad must fully reset the direct sinks
+        flat.zero_grad()
+        _loss(m, gpu).backward()
+    names = [n for n, _ in m.named_parameters()]
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offsets[names.index(n)]
+        if q.grad is None:          # parameter unused by this loss (map_augment without labels)
+            assert float(p.grad.abs().max()) == 0, n
+            continue
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()) + 1e-12, msg=n)
+
+    # reference optimiser on CPU copies
+    cpu = copy.deepcopy(ref).cpu()
+    for pc, pr in zip(cpu.parameters(), ref.parameters()):
+        pc.grad = pr.grad.detach().cpu().clone() if pr.grad is not None else torch.zeros_like(pc)
+    ema_ref = [p.detach().clone() for p in cpu.parameters()]
+    topt = torch.optim.AdamW(cpu.parameters(), lr=3e-4, weight_decay=1e-2)
+    opt = FusedAdamWEMA(flat, lr=3e-4, weight_decay=1e-2, max_norm=1.0, ema=True)
+    for step in range(3):
+        total = torch.nn.utils.clip_grad_norm_(cpu.parameters(), 1.0)
+        topt.step()
+        for e, p in zip(ema_ref, cpu.parameters()):
+            e.lerp_(p.detach(), 1 - 0.9)
+        opt.step(ema_decay=0.9)
+        assert abs(opt.grad_norm() - float(total)) <= 1e-4 * float(total)
+        # both sides keep the SAME gradients for the next step (clip_grad_norm_ scaled the CPU copy in place)
+        for pc, pr in zip(cpu.parameters(), ref.parameters()):
+            pc.grad = pr.grad.detach().cpu().clone() if pr.grad is not None else torch.zeros_like(pc)
+    for (n, p), pc, e in zip(m.named_parameters(), cpu.parameters(), ema_ref):
+        torch.testing.assert_close(p.detach().cpu(), pc.detach(), rtol=1e-4, atol=1e-6, msg=n)
+        o = flat.offsets[names.index(n)]
+        torch.testing.assert_close(opt.ema[o:o + p.numel()].view(p.shape).cpu(), e, rtol=1e-4, atol=1e-6, msg=n)
+    # packed weights must have been invalidated: a forward now uses the updated parameters
+    y_new = m(fill.hash_tensor((2, 3, 32, 32), "x", 1.0).to(gpu), torch.tensor([0.05, 0.7], device=gpu))[0]
+    m2 = _model(gpu)
+    m2.load_state_dict(m.state_dict())
+    y_chk = m2(fill.hash_tensor((2, 3, 32, 32), "x", 1.0).to(gpu), torch.tensor([0.05, 0.7], device=gpu))[0]
+    torch.testing.assert_close(y_new, y_chk, rtol=1e-5, atol=1e-6)
