@@ -25,7 +25,7 @@ namespace {
 
 struct IgemmP {
   const float* x; const float* w; const float* bias; const float* res; float* y;
-  int M, N, H, W, Hin, Win, Cin, ldx, K, ldy, ldr, ks, up, wrows, tilesN;
+  int M, N, H, W, Hin, Win, Cin, ldx, K, ldy, ldr, ks, up, wrows, tilesN, xbytes, wbytes;
 };
 
 constexpr int LDSS = 36;   // floats per LDS row (32 + 4 pad)
@@ -42,16 +42,35 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int lr = lane & 31, lh = lane >> 5;
-  const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+  int bid = blockIdx.x;
+#ifdef ADM_EXP_XCD
+  {   // XCD-aware remap (bijective): blocks dealt round-robin over 8 XCDs -> give each XCD a contiguous chunk
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+#endif
+#ifdef ADM_EXP_TMMAJOR
+  const int tilesM = gridDim.x / p.tilesN;
+  const int tm = bid % tilesM, tn = bid / tilesM;
+#else
+  const int tn = bid % p.tilesN, tm = bid / p.tilesN;
+#endif
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- loader state: each thread owns float4 column c4 of rows r0 + 32 i ----
-  // Per row: a base pointer at tap (0,0) and a 9-bit mask of the taps that fall inside the image, both
-  // computed once; per K-step only `mask >> tap`, one add and the load remain.  Out-of-image taps read a
-  // valid dummy address (the row's centre pixel) and are zeroed with a select: no divergent branches.
+  // Addressing is done with raw BUFFER loads so that almost no vector ALU work is left in the K loop
+  // (on gfx950 the fp32 MFMA shares the SIMD's fp32 lanes: every VALU instruction in the loop is MFMA time
+  // lost -- measured: the staging code cost 17 % before this):
+  //   * per row a 32-bit byte offset `voff` that already includes the current tap; it is recomputed only when
+  //     the tap changes (every Cin/32 K-steps), and set to 0x80000000 for rows / taps outside the image;
+  //   * the channel-chunk offset rides in the instruction's scalar offset;
+  //   * the buffer descriptor's range check returns ZERO for the 0x80000000 rows, which implements the zero
+  //     padding (and the M / N edge masking) with no select instructions at all.
   const int c4 = tid & 7, r0 = tid >> 3;
-  const float* a_base[AI];
-  unsigned a_mask[AI];
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.wbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_pix[AI], a_mask[AI], a_voff[AI];
   const int pad = p.ks >> 1;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
@@ -74,60 +93,58 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
         mask = 1u;
       }
     }
+    // for the fused nearest-x2 the tap offset depends on the parity of (oy, ox): keep it in the high bits
+    if (UP) mask |= ((unsigned)(oy & 1) << 16) | ((unsigned)(ox & 1) << 17);
     a_mask[i] = mask;
-    // pointer to input pixel (oy, ox) [or (oy/2, ox/2) for the fused nearest-x2], channel quad c4
     int py = UP ? (oy >> 1) : oy, px = UP ? (ox >> 1) : ox;
-    a_base[i] = p.x + ((long)(b * p.Hin + py) * p.Win + px) * p.ldx + c4 * 4;
-    // for `up`, the tap offset depends on the parity of (oy, ox); keep those in the mask's high bits
-    if (UP) a_mask[i] |= ((unsigned)(oy & 1) << 16) | ((unsigned)(ox & 1) << 17);
+    a_pix[i] = (unsigned)(((b * p.Hin + py) * p.Win + px) * p.ldx + c4 * 4) * 4u;     // byte offset of the centre pixel
+    a_voff[i] = OOB;
   }
   const int cchunks = p.Cin >> 5;
   const int KT = p.ks * p.ks * cchunks;
-  const float* b_base[BI];
-  bool b_ok[BI];
+  unsigned b_voff[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     int n = n0 + r0 + 32 * i;
-    b_ok[i] = n < p.wrows;
-    b_base[i] = p.w + (long)(b_ok[i] ? n : 0) * p.K + c4 * 4;
+    b_voff[i] = (n < p.wrows) ? (unsigned)(n * p.K + c4 * 4) * 4u : OOB;
   }
 
   f32x4 ra[AI], rb[BI];
   int ld_tap = 0, ld_cc = 0;       // (tap, channel chunk) of the NEXT stage to load: no division per stage
-  int st_tap = 0;                  // tap of the stage held in ra/rb (for the zero-padding select at store time)
-  // Loads are issued raw (always from a valid address); the out-of-image select is applied only when the
-  // registers are written to LDS, AFTER the MFMAs of the current stage, so the loads stay in flight.
   auto load_stage = [&]() {
-    const int tap = ld_tap, c0 = ld_cc << 5;
-    int dy = 0, dx = 0;
-    if (p.ks == 3) { dy = tap / 3 - pad; dx = tap - (tap / 3) * 3 - pad; }
-    const long tap_off = ((long)dy * p.Win + dx) * p.ldx + c0;      // wave-uniform (non-up case)
+    const int tap = ld_tap;
+    if (ld_cc == 0) {              // new tap: rebuild the per-row offsets (wave-uniform branch, every Cin/32 steps)
+      int dy = 0, dx = 0;
+      if (p.ks == 3) { dy = tap / 3 - pad; dx = tap - (tap / 3) * 3 - pad; }
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const bool v = (a_mask[i] >> tap) & 1u;
-      long off = tap_off;
-      if (UP) {     // input pixel of output (oy+dy, ox+dx) is ((oy+dy)>>1, (ox+dx)>>1)
-        int py = (int)((a_mask[i] >> 16) & 1u), px = (int)((a_mask[i] >> 17) & 1u);
-        int qy = ((py + dy + 2) >> 1) - 1, qx = ((px + dx + 2) >> 1) - 1;     // floor((parity + d) / 2)
-        off = ((long)qy * p.Win + qx) * p.ldx + c0;
+      for (int i = 0; i < AI; ++i) {
+        const bool v = (a_mask[i] >> tap) & 1u;
+        int off = (dy * p.Win + dx) * p.ldx;
+        if (UP) {   // input pixel of output (oy+dy, ox+dx) is ((oy+dy)>>1, (ox+dx)>>1): floor((parity + d) / 2)
+          int py = (int)((a_mask[i] >> 16) & 1u), px = (int)((a_mask[i] >> 17) & 1u);
+          int qy = ((py + dy + 2) >> 1) - 1, qx = ((px + dx + 2) >> 1) - 1;
+          off = (qy * p.Win + qx) * p.ldx;
+        }
+        a_voff[i] = v ? a_pix[i] + (unsigned)(off * 4) : OOB;
       }
-      ra[i] = *reinterpret_cast<const f32x4*>(a_base[i] + (v ? off : (long)c0));
     }
-    const int koff = tap * p.Cin + c0;
+    const int c0b = ld_cc << 7;                                  // 32 floats = 128 bytes per chunk
+    const int kb = (tap * p.Cin) * 4 + c0b;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_base[i] + koff);
-    st_tap = tap;
+    for (int i = 0; i < AI; ++i)
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[i], c0b, 0));
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)b_voff[i], kb, 0));
     if (++ld_cc == cchunks) { ld_cc = 0; ++ld_tap; }
   };
   auto store_stage = [&](int buf) {
     float* Ab = As + buf * BM * LDSS;
     float* Bb = Bs + buf * BN * LDSS;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < AI; ++i)
-      *reinterpret_cast<f32x4*>(&Ab[(r0 + 32 * i) * LDSS + c4 * 4]) = ((a_mask[i] >> st_tap) & 1u) ? ra[i] : zero;
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&Ab[(r0 + 32 * i) * LDSS + c4 * 4]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bb[(r0 + 32 * i) * LDSS + c4 * 4]) = b_ok[i] ? rb[i] : zero;
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bb[(r0 + 32 * i) * LDSS + c4 * 4]) = rb[i];
   };
 
   f32x16 acc[MT][NT];
@@ -144,9 +161,43 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
 
   for (int s = 0; s < KT; ++s) {
     const int buf = s & 1;
+#ifndef ADM_EXP_NOLOAD
     if (s + 1 < KT) load_stage();
+#endif
     const float* Ab = As + buf * BM * LDSS + (wm * MT * 32 + lr) * LDSS + lh * 4;
     const float* Bb = Bs + buf * BN * LDSS + (wn * NT * 32 + lr) * LDSS + lh * 4;
+#ifdef ADM_EXP_PREFETCH
+    {
+      f32x4 a[2][MT], b[2][NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g < 3) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) a[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS + (g + 1) * 8);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS + (g + 1) * 8);
+        }
+#ifdef ADM_EXP_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][k], b[cur][j][k], acc[i][j], 0, 0, 0);
+#ifdef ADM_EXP_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+      }
+    }
+#else
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 a[MT], b[NT];
@@ -154,6 +205,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
       for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS + g * 8);
 #pragma unroll
       for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS + g * 8);
+#ifdef ADM_EXP_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -161,9 +215,17 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
+#ifdef ADM_EXP_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
+#endif
+#ifndef ADM_EXP_NOLOAD
     if (s + 1 < KT) store_stage(buf ^ 1);
+#endif
+#ifndef ADM_EXP_NOBARRIER
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5) ----
@@ -250,19 +312,23 @@ extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, 
   p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.K = ks * ks * Cin; p.ldy = ldy; p.ldr = ldr; p.ks = ks; p.up = up; p.wrows = wrows;
   p.tilesN = 0;
+  const long xb = (long)B * p.Hin * p.Win * ldx * 4, wb = (long)wrows * p.K * 4;
+  if (xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;     // 32-bit buffer offsets; 0x80000000 must stay out of range
+  p.xbytes = (int)xb; p.wbytes = (int)wb;
   if (tile < 0) {
     // Cost model: time ~ rounds * (work of one tile) / (per-tile efficiency), rounds = ceil(tiles / resident slots).
     // Resident workgroups per CU follow from the LDS footprint (2 for the 128-row tiles, 4 for 64x64).
     struct Cand { int id, bm, bn, per_cu; double eff; };
-    const Cand cands[4] = {{0, 128, 128, 2, 1.00}, {1, 128, 96, 2, 0.97}, {2, 64, 64, 4, 0.80}, {3, 128, 32, 4, 0.70}};
+    const Cand cands[4] = {{0, 128, 128, 2, 1.00}, {1, 128, 96, 2, 0.97}, {2, 64, 64, 4, 0.90}, {3, 128, 32, 4, 0.70}};
     double best = 1e300;
     for (const Cand& c : cands) {
       long tiles = (long)adm_cdiv(p.M, c.bm) * adm_cdiv(N, c.bn);
       long slots = 256L * c.per_cu;
       long rounds = (tiles + slots - 1) / slots;
       // measured: a workgroup alone on a CU takes as long as two sharing it (it cannot hide its own
-      // barrier stalls), so time goes by whole rounds of resident slots
-      double t = (double)rounds * c.bm * c.bn / c.eff;
+      // barrier stalls), so time goes by whole rounds of resident slots; a round keeps a CU busy for the
+      // work of all its resident workgroups
+      double t = (double)rounds * c.per_cu * c.bm * c.bn / c.eff;
       if (t < best) { best = t; tile = c.id; }
     }
   }

@@ -17,7 +17,7 @@ namespace {
 
 struct WgradP {
   const float* x; const float* dy; float* dwp;
-  int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh;
+  int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes;
 };
 
 template <int TM, int TN>
@@ -45,40 +45,86 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
 
   const int a_c = tid % AQ, a_r = tid / AQ;
   const int b_c = tid % BQ, b_r = tid / BQ;
-  const bool a_cok = co0 + a_c * 4 < p.Cout;
-  const bool b_cok = ci0 + b_c * 4 < p.Cin;
+  // Raw buffer loads (see conv_igemm.hip): 32-bit offsets, and the descriptor's range check supplies the
+  // zeros for out-of-image taps, channel-edge tiles and pixels past the end -- no selects, little VALU.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dybytes, 0x00020000);
+  unsigned a_voff[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+    a_voff[i] = (co0 + a_c * 4 < p.Cout) ? (unsigned)((a_r + i * AR) * p.lddy + co0 + a_c * 4) * 4u : OOB;
+  const unsigned b_colb = (ci0 + b_c * 4 < p.Cin) ? (unsigned)(ci0 + b_c * 4) * 4u : OOB;
+  // fast path state (see load_stage)
+  const bool fast = p.lw >= 0 && p.W <= 32 && !p.up;
+  const int shift = (dy_ * p.W + dx_) * p.ldx;                       // floats; may be negative
+  const __amdgpu_buffer_rsrc_t rs_xt =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, p.xbytes - shift * 4, 0x00020000);
+  unsigned b_voff[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int r = b_r + i * BR;
+    const bool xv = (unsigned)((r & (p.W - 1)) + dx_) < (unsigned)p.W;
+    b_voff[i] = (xv && b_colb != OOB) ? (unsigned)(r * p.ldx) * 4u + b_colb : OOB;
+  }
 
   f32x4 ra[AI], rb[BI];
   auto load_stage = [&](int s) {
     const int pb = pbeg + (s << 5);
+    const int a_soff = pb * p.lddy * 4;       // rows past P fall outside the descriptor -> zeros
+    if (pb + 32 <= pend) {          // wave-uniform: only a ragged last stage needs the per-row test
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int pp = pb + a_r + i * AR;
-      bool v = a_cok && pp < pend;
-      ra[i] = v ? *reinterpret_cast<const f32x4*>(p.dy + (long)pp * p.lddy + co0 + a_c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+      for (int i = 0; i < AI; ++i)
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_voff[i], a_soff, 0));
+    } else {
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      int pp = pb + b_r + i * BR;
-      bool v = b_cok && pp < pend;
-      int ppp = v ? pp : 0;
-      int ox, oy, b;
-      if (p.lw >= 0) {            // power-of-two image: shifts instead of integer division
-        ox = ppp & (p.W - 1);
-        int t = ppp >> p.lw;
-        oy = t & (p.H - 1);
-        b = t >> p.lh;
-      } else {
-        ox = ppp % p.W;
-        int t = ppp / p.W;
-        oy = t % p.H;
-        b = t / p.H;
+      for (int i = 0; i < AI; ++i) {
+        unsigned vo = (pb + a_r + i * AR < pend) ? a_voff[i] : OOB;
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)vo, a_soff, 0));
       }
-      int iy = oy + dy_, ix = ox + dx_;
-      v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      if (p.up) { iy >>= 1; ix >>= 1; }
-      const float* ptr = p.x + ((long)(b * p.Hin + iy) * p.Win + ix) * p.ldx + ci0 + b_c * 4;
-      rb[i] = v ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (fast) {
+      // power-of-two image, W <= 32, no up-sampling: the column test and the byte offset inside the stage are
+      // per-thread constants, the stage's pixel base rides in the scalar offset and the tap shift is folded into
+      // the descriptor's base -> per row only the image-row test (and nothing at all for the centre-row taps).
+      const int b_soff = pb * p.ldx * 4;
+      const int U = pb >> p.lw;
+      const bool full = pb + 32 <= pend;
+      if (dy_ == 0 && full) {
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+          rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)b_voff[i], b_soff, 0));
+      } else {
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+          const int r = b_r + i * BR;
+          const int iy = ((U + (r >> p.lw)) & (p.H - 1)) + dy_;
+          const bool v = (unsigned)iy < (unsigned)p.H && (full || pb + r < pend);
+          rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(v ? b_voff[i] : OOB), b_soff, 0));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        int pp = pb + b_r + i * BR;
+        int ox, oy, b;
+        if (p.lw >= 0) {            // power-of-two image: shifts instead of integer division
+          ox = pp & (p.W - 1);
+          int t = pp >> p.lw;
+          oy = t & (p.H - 1);
+          b = t >> p.lh;
+        } else {
+          ox = pp % p.W;
+          int t = pp / p.W;
+          oy = t % p.H;
+          b = t / p.H;
+        }
+        int iy = oy + dy_, ix = ox + dx_;
+        bool v = pp < pend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        if (p.up) { iy >>= 1; ix >>= 1; }
+        unsigned voff = v ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.ldx) * 4u + b_colb : OOB;
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0));
+      }
     }
   };
   auto store_stage = [&](int buf) {
@@ -161,6 +207,9 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
   p.x = x; p.dy = dy; p.dwp = dwp;
   p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.ks = ks; p.up = up; p.tilesN = 0;
+  const long xb = (long)B * p.Hin * p.Win * ldx * 4, db = (long)p.P * lddy * 4;
+  if (xb >= (1L << 31) || db >= (1L << 31)) return ADM_EINVAL;      // 32-bit buffer offsets
+  p.xbytes = (int)xb; p.dybytes = (int)db;
   auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
   p.lw = ilog2(W); p.lh = ilog2(H);
   if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
@@ -177,6 +226,9 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
   splits = (p.P + chunk - 1) / chunk;
   p.chunk = chunk;
   p.atomic = splits > 1;
+  if (p.atomic &&
+      hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * ks * ks * Cin, stream) != hipSuccess)
+    return ADM_ELAUNCH;
   if (TM == 128 && TN == 128) return launch_wgrad<128, 128>(p, splits, stream);
   if (TM == 128 && TN == 64) return launch_wgrad<128, 64>(p, splits, stream);
   if (TM == 64 && TN == 128) return launch_wgrad<64, 128>(p, splits, stream);

@@ -170,7 +170,7 @@ class _Conv(torch.autograd.Function):
             else:
                 dx = dxf
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((cop, ks * ks * cip), device=dy.device, dtype=_f32)
+            dwp = _new((cop, ks * ks * cip), dy)
             with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"wgrad P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                 call("adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
             sink = _direct_grad(weight)

@@ -64,11 +64,14 @@ class BucketedGradReducer:
     for the side stream.  Works on CPU tensors with gloo too (synchronously), which is how the
     world_size-2 tests cover it."""
 
-    def __init__(self, flat: FlatParams, bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, flat: FlatParams, bucket_bytes: int = 64 << 20, group=None, force: bool = False):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # ``force`` runs the full hook / side-stream / all-reduce machinery even at world size 1
+        # (a 1-rank RCCL communicator): lets a single-GPU box exercise the multi-GPU code path.
+        self.active = dist.is_initialized() and (self.world > 1 or force)
         self.cuda = flat.grad.is_cuda
-        self.side = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.side = torch.cuda.Stream() if (self.cuda and self.active) else None
         self.buckets = []             # (start, end, n_params)
         self.param_bucket = {}
         cap = max(1, bucket_bytes // 4)
@@ -88,7 +91,7 @@ class BucketedGradReducer:
         self.pending = [0] * len(self.buckets)
         self.enabled = True
         self.handles = []
-        if self.world > 1:
+        if self.active:
             for idx, p in enumerate(flat.params):
                 hook = self._make_hook(idx)
                 p.register_post_accumulate_grad_hook(hook)     # gradients that arrive through autograd
@@ -119,7 +122,7 @@ class BucketedGradReducer:
     def finish(self):
         """Call after backward: launches any bucket whose hooks did not all fire (parameters without a
         gradient this step) and joins the side stream."""
-        if self.world > 1 and self.enabled:
+        if self.active and self.enabled:
             for b in range(len(self.buckets)):
                 if self.pending[b] != self.buckets[b][2]:
                     self._launch(b)

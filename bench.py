@@ -126,9 +126,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = bool(os.environ.get("ADM_FORCE_DIST"))       # exercise the RCCL path on a 1-GPU box
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from adm_amd import hip, ops
     from adm_amd.optim import BucketedGradReducer, FlatParams, FusedAdamWEMA, ema_decay_at, lr_lambda
@@ -137,9 +140,10 @@ def main():
     dpm = build_model(dev, args.small)
     dpm.train()
     flat = FlatParams(dpm)
-    if world > 1:   # identical start on every rank
+    if use_dist:    # identical start on every rank
         dist.broadcast(flat.flat, src=0)
-    reducer = BucketedGradReducer(flat)
+    reducer = BucketedGradReducer(flat, force=force_dist)
+    log(f"world={world} rank={rank} buckets={len(reducer.buckets)} reducer_active={reducer.active}")
     opt = FusedAdamWEMA(flat, lr=1e-4, weight_decay=1e-4, max_norm=1.0, ema=(rank == 0))
     B = args.batch
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -157,7 +161,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,12 +175,12 @@ def main():
         loss = train_step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     if args.profile_only:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     ms_per_step = dt / args.steps * 1e3
@@ -228,7 +232,7 @@ def main():
         img = dpm.sample(batch_size=B)
         barrier()
         st = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([st], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             st = float(tmax)
@@ -251,7 +255,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

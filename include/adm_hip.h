@@ -40,8 +40,8 @@ int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float
                  int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                  int ks, int up, int tile, hipStream_t stream);
 
-/* dwp[Cout][ks*ks][Cin] += sum_pixels dy[p][co] * x[p+tap][ci]  (atomic fp32 accumulation over
- * `splits` pixel ranges; caller zero-fills dwp).  The weight-gradient of the conv above
+/* dwp[Cout][ks*ks][Cin] = sum_pixels dy[p][co] * x[p+tap][ci]  (atomic fp32 accumulation over
+ * `splits` pixel ranges; dwp is overwritten: the call zero-fills it when it splits).  The weight-gradient of the conv above
  * (autograd of F.conv2d in the reference).  Cout, Cin multiples of 32. */
 int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
                    int Cout, int lddy, int ks, int up, int splits, hipStream_t stream);

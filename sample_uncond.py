@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""MI355X counterpart of the reference's unconditional sampler (/root/reference/sample_uncond.py).
+
+``python sample_uncond.py --cfg <yaml>``: builds unet + DDPM from the YAML exactly as the trainer does,
+loads ``cfg.sampler.ckpt_path`` (taking the EMA weights when ``sampler.use_ema``: the checkpoint's 'ema'
+dict with the ``ema_model.`` prefix stripped, reference :131-147), then draws ``sampler.sample_num`` images
+in batches of ``sampler.batch_size`` with ``model.sample(batch_size=...)`` (10-step deterministic sampler)
+and writes them as PNGs named ``f'{i: 010d}.png'`` (reference :168-173 -- note the space flag).
+Each rank samples its own disjoint id range with its own seed; there are no collectives (the reference
+lets every rank write the same names).
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from adm_amd.ddm.utils import construct_class_by_name  # noqa: E402
+from train_uncond_dpm import Cfg  # noqa: E402
+
+
+def load_weights(model, path, use_ema, device):
+    data = torch.load(path, map_location=device, weights_only=True)
+    if use_ema and "ema" in data:
+        sd = {k[len("ema_model."):]: v for k, v in data["ema"].items() if k.startswith("ema_model.")}
+    else:
+        sd = data["model"] if "model" in data else data
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    print(f"loaded {path}: {len(missing)} missing, {len(unexpected)} unexpected keys")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", required=True)
+    ap.add_argument("--max-batches", type=int, default=None)
+    args = ap.parse_args()
+    with open(args.cfg) as f:
+        cfg = Cfg(yaml.load(f, Loader=yaml.SafeLoader))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.manual_seed(42 + rank)
+    mc = cfg.model
+    unet = construct_class_by_name(**{k: v for k, v in mc.unet.items()})
+    dpm = construct_class_by_name(model=unet, cfg=mc, class_name=mc.class_name,
+                                  **{k: v for k, v in mc.items() if k not in ("class_name", "unet")}).to(device).eval()
+    s = cfg.sampler
+    if s.get("ckpt_path") and os.path.exists(s.ckpt_path):
+        load_weights(dpm, s.ckpt_path, s.get("use_ema", True), device)
+    else:
+        print("no checkpoint found: sampling from the initialised weights")
+    out = s.save_folder
+    os.makedirs(out, exist_ok=True)
+    from PIL import Image
+    per_rank = int(s.sample_num) // world
+    bs = int(s.batch_size)
+    n_batches = (per_rank + bs - 1) // bs
+    if args.max_batches is not None:
+        n_batches = min(n_batches, args.max_batches)
+    img_id, t0, done = rank * per_rank, time.time(), 0
+    for _ in range(n_batches):
+        real_bs = min(bs, per_rank - done)
+        batch = dpm.sample(batch_size=real_bs)
+        arr = (batch.clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+        for j in range(real_bs):
+            Image.fromarray(arr[j]).save(os.path.join(out, f"{img_id: 010d}.png"))
+            img_id += 1
+        done += real_bs
+    torch.cuda.synchronize()
+    print(f"rank {rank}: {done} images in {time.time() - t0:.1f}s ({done / (time.time() - t0):.1f} images/sec incl. PNG writes)")
+
+
+if __name__ == "__main__":
+    main()

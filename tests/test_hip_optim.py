@@ -50,9 +50,12 @@ def test_direct_flat_gradients_and_fused_adamw():
         torch.testing.assert_close(p.grad, q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()) + 1e-12, msg=n)
 
     # reference optimiser on CPU copies
+    # (the CPU optimiser is fed the flat buffer's gradients bit for bit: Adam's m/sqrt(v) turns a sign flip of
+    #  a ~0 gradient -- e.g. from split-K atomics ordering -- into a full +-lr step, which is not what is tested)
     cpu = copy.deepcopy(ref).cpu()
-    for pc, pr in zip(cpu.parameters(), ref.parameters()):
-        pc.grad = pr.grad.detach().cpu().clone() if pr.grad is not None else torch.zeros_like(pc)
+    g_cpu = [p.grad.detach().cpu().clone() for p in m.parameters()]
+    for pc, g in zip(cpu.parameters(), g_cpu):
+        pc.grad = g.clone()
     ema_ref = [p.detach().clone() for p in cpu.parameters()]
     topt = torch.optim.AdamW(cpu.parameters(), lr=3e-4, weight_decay=1e-2)
     opt = FusedAdamWEMA(flat, lr=3e-4, weight_decay=1e-2, max_norm=1.0, ema=True)
