@@ -20,7 +20,7 @@ struct WgradP {
   int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes;
 };
 
-template <int TM, int TN>
+template <int TM, int TN, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
   constexpr int WM = 2, WN = 2;
   constexpr int MT = TM / (WM * 32), NT = TN / (WN * 32);
@@ -56,7 +56,6 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
     a_voff[i] = (co0 + a_c * 4 < p.Cout) ? (unsigned)((a_r + i * AR) * p.lddy + co0 + a_c * 4) * 4u : OOB;
   const unsigned b_colb = (ci0 + b_c * 4 < p.Cin) ? (unsigned)(ci0 + b_c * 4) * 4u : OOB;
   // fast path state (see load_stage)
-  const bool fast = p.lw >= 0 && p.W <= 32 && !p.up;
   const int shift = (dy_ * p.W + dx_) * p.ldx;                       // floats; may be negative
   const __amdgpu_buffer_rsrc_t rs_xt =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, p.xbytes - shift * 4, 0x00020000);
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)vo, a_soff, 0));
       }
     }
-    if (fast) {
+    if constexpr (FAST) {
       // power-of-two image, W <= 32, no up-sampling: the column test and the byte offset inside the stage are
       // per-thread constants, the stage's pixel base rides in the scalar offset and the tap shift is folded into
       // the descriptor's base -> per row only the image-row test (and nothing at all for the centre-row taps).
@@ -190,7 +189,9 @@ template <int TM, int TN>
 int launch_wgrad(WgradP p, int splits, hipStream_t st) {
   p.tilesN = adm_cdiv(p.Cin, TN);
   dim3 grid(adm_cdiv(p.Cout, TM) * p.tilesN, p.ks * p.ks, splits);
-  hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN>), grid, dim3(256), 0, st, p);
+  const bool fast = p.lw >= 0 && p.W <= 32 && !p.up;       // see load_stage
+  if (fast) hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN, false>), grid, dim3(256), 0, st, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
