@@ -1,14 +1,22 @@
 // Weight gradient of the 3x3 / 1x1 / Linear layers on the fp32-input MFMA (gfx950).
 //
-//   dWp[co][tap][ci] += sum_{p in split} dY[p][co] * X[pix(p) + tap][ci]
+//   dWp[co][tap][ci] = sum_p dY[p][co] * X[pix(p) + tap][ci]
 //
-// GEMM view: M' = Cout (rows of dY^T), N' = Cin, K' = pixels.  Both operands arrive pixel-major
-// (NHWC), i.e. "k-major" with the m / n index contiguous, so tiles are staged into LDS exactly as
-// they lie in memory ([32 pixels][TM] and [32 pixels][TN]) and MFMA fragments are read with
-// conflict-free ds_read_b32 (lane = consecutive channel; the two wave halves read pixel 2s and 2s+1).
-// The reduction over pixels is split across gridDim.z; partial tiles are combined with fp32 global
-// atomics shaped as 128-byte row segments (the full-rate shape on MI355X), or plain stores when
-// splits == 1.  Autograd counterpart of F.conv2d's weight gradient in the reference
+// GEMM view: M' = Cout, N' = Cin, K' = pixels.  Both operands arrive pixel-major (NHWC), i.e. with the
+// REDUCTION index outermost, while the MFMA wants each lane to supply consecutive k of one row.  The tiles
+// are therefore TRANSPOSED on their way into LDS ([channel][32 pixels + 4 pad]) so that the compute loop is
+// the same VALU-free loop as the forward kernel (conv_igemm.hip): per 32-pixel step only conflict-free
+// ds_read_b128 fragment reads with immediate offsets and 64 MFMAs per wave -- on gfx950 the fp32 MFMA shares
+// the SIMD's fp32 lanes, so any vector-ALU instruction left in the loop is MFMA time lost.
+//
+//   * global -> registers: raw buffer loads, lane = (pixel = lane & 15, channel quad = lane >> 4): 16 pixels
+//     x 64 B per wave instruction; the descriptor's range check returns zeros for out-of-image taps,
+//     channel-edge tiles and pixels past the end (no selects);
+//   * registers -> LDS: four ds_write_b32 per float4, to rows c..c+3 at column `pixel`; with the 36-float row
+//     stride a 32-lane group (2 quads x 16 pixels) covers all 32 banks exactly once;
+//   * the reduction over pixels is split across gridDim.z; partial tiles are combined with fp32 global atomics
+//     shaped as 128-byte row segments, or plain stores when splits == 1.
+// Autograd counterpart of F.conv2d's weight gradient in the reference
 // (/root/reference/unet/uncond_unet.py:98-110 under loss.backward()).
 #include "common.h"
 #include "../../include/adm_hip.h"
@@ -20,15 +28,15 @@ struct WgradP {
   int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes;
 };
 
+constexpr int WLDS = 36;   // floats per LDS row: 32 pixels + 4 pad
+
 template <int TM, int TN, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
   constexpr int WM = 2, WN = 2;
   constexpr int MT = TM / (WM * 32), NT = TN / (WN * 32);
-  constexpr int AQ = TM / 4, BQ = TN / 4;              // float4 per tile row
-  constexpr int AR = 256 / AQ, BR = 256 / BQ;          // rows covered per pass
-  constexpr int AI = 32 / AR, BI = 32 / BR;            // passes
-  __shared__ __attribute__((aligned(16))) float As[2][32][TM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][32][TN];
+  constexpr int AI = TM / 32, BI = TN / 32;            // float4 per thread per stage (32 px * T/4 quads / 256)
+  __shared__ __attribute__((aligned(16))) float As[2][TM][WLDS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TN][WLDS];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -43,52 +51,56 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
   if (pbeg >= pend) return;
   const int KT = (pend - pbeg + 31) >> 5;
 
-  const int a_c = tid % AQ, a_r = tid / AQ;
-  const int b_c = tid % BQ, b_r = tid / BQ;
-  // Raw buffer loads (see conv_igemm.hip): 32-bit offsets, and the descriptor's range check supplies the
-  // zeros for out-of-image taps, channel-edge tiles and pixels past the end -- no selects, little VALU.
+  // wave instruction q = wid*I + i covers pixels (q&1)*16 + (lane&15) and channel quads (q>>1)*4 + (lane>>4)
+  const int lk = lane & 15, lq = lane >> 4;
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dybytes, 0x00020000);
-  unsigned a_voff[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i)
-    a_voff[i] = (co0 + a_c * 4 < p.Cout) ? (unsigned)((a_r + i * AR) * p.lddy + co0 + a_c * 4) * 4u : OOB;
-  const unsigned b_colb = (ci0 + b_c * 4 < p.Cin) ? (unsigned)(ci0 + b_c * 4) * 4u : OOB;
-  // fast path state (see load_stage)
-  const int shift = (dy_ * p.W + dx_) * p.ldx;                       // floats; may be negative
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
+  const int shift = (dy_ * p.W + dx_) * p.ldx;                       // floats; may be negative (FAST path only)
   const __amdgpu_buffer_rsrc_t rs_xt =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, p.xbytes - shift * 4, 0x00020000);
-  unsigned b_voff[BI];
+
+  int a_pix[AI], a_row[AI], b_pix[BI], b_row[BI];     // stage-local pixel, tile-local first channel of the quad
+  unsigned a_voff[AI], b_voff[BI], b_colb[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int q = wid * AI + i;
+    a_pix[i] = (q & 1) * 16 + lk;
+    a_row[i] = ((q >> 1) * 4 + lq) * 4;
+    a_voff[i] = (co0 + a_row[i] < p.Cout) ? (unsigned)(a_pix[i] * p.lddy + co0 + a_row[i]) * 4u : OOB;
+  }
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int r = b_r + i * BR;
-    const bool xv = (unsigned)((r & (p.W - 1)) + dx_) < (unsigned)p.W;
-    b_voff[i] = (xv && b_colb != OOB) ? (unsigned)(r * p.ldx) * 4u + b_colb : OOB;
+    const int q = wid * BI + i;
+    b_pix[i] = (q & 1) * 16 + lk;
+    b_row[i] = ((q >> 1) * 4 + lq) * 4;
+    b_colb[i] = (ci0 + b_row[i] < p.Cin) ? (unsigned)(ci0 + b_row[i]) * 4u : OOB;
+    const bool xv = (unsigned)((b_pix[i] & (p.W - 1)) + dx_) < (unsigned)p.W;      // FAST: column test is per-thread constant
+    b_voff[i] = (xv && b_colb[i] != OOB) ? (unsigned)(b_pix[i] * p.ldx) * 4u + b_colb[i] : OOB;
   }
 
   f32x4 ra[AI], rb[BI];
   auto load_stage = [&](int s) {
     const int pb = pbeg + (s << 5);
-    const int a_soff = pb * p.lddy * 4;       // rows past P fall outside the descriptor -> zeros
-    if (pb + 32 <= pend) {          // wave-uniform: only a ragged last stage needs the per-row test
+    const bool full = pb + 32 <= pend;          // wave-uniform: only a ragged last stage needs per-row tests
+    const int a_soff = pb * p.lddy * 4;
+    if (full) {
 #pragma unroll
       for (int i = 0; i < AI; ++i)
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_voff[i], a_soff, 0));
     } else {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        unsigned vo = (pb + a_r + i * AR < pend) ? a_voff[i] : OOB;
+        unsigned vo = (pb + a_pix[i] < pend) ? a_voff[i] : OOB;
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)vo, a_soff, 0));
       }
     }
     if constexpr (FAST) {
-      // power-of-two image, W <= 32, no up-sampling: the column test and the byte offset inside the stage are
-      // per-thread constants, the stage's pixel base rides in the scalar offset and the tap shift is folded into
-      // the descriptor's base -> per row only the image-row test (and nothing at all for the centre-row taps).
+      // power-of-two image, W <= 32, no up-sampling: the byte offset inside the stage is a per-thread constant,
+      // the stage's pixel base rides in the scalar offset and the tap shift is folded into the descriptor's
+      // base -> per load only the image-row test (nothing at all for the centre-row taps).
       const int b_soff = pb * p.ldx * 4;
       const int U = pb >> p.lw;
-      const bool full = pb + 32 <= pend;
       if (dy_ == 0 && full) {
 #pragma unroll
         for (int i = 0; i < BI; ++i)
@@ -96,41 +108,36 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
       } else {
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-          const int r = b_r + i * BR;
-          const int iy = ((U + (r >> p.lw)) & (p.H - 1)) + dy_;
-          const bool v = (unsigned)iy < (unsigned)p.H && (full || pb + r < pend);
+          const int iy = ((U + (b_pix[i] >> p.lw)) & (p.H - 1)) + dy_;
+          const bool v = (unsigned)iy < (unsigned)p.H && (full || pb + b_pix[i] < pend);
           rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(v ? b_voff[i] : OOB), b_soff, 0));
         }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
-        int pp = pb + b_r + i * BR;
-        int ox, oy, b;
-        if (p.lw >= 0) {            // power-of-two image: shifts instead of integer division
-          ox = pp & (p.W - 1);
-          int t = pp >> p.lw;
-          oy = t & (p.H - 1);
-          b = t >> p.lh;
-        } else {
-          ox = pp % p.W;
-          int t = pp / p.W;
-          oy = t % p.H;
-          b = t / p.H;
-        }
+        const int pp = pb + b_pix[i];
+        int ox = pp % p.W;
+        int t = pp / p.W;
+        int oy = t % p.H;
+        int b = t / p.H;
         int iy = oy + dy_, ix = ox + dx_;
-        bool v = pp < pend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        bool v = pp < pend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && b_colb[i] != OOB;
         if (p.up) { iy >>= 1; ix >>= 1; }
-        unsigned voff = v ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.ldx) * 4u + b_colb : OOB;
+        unsigned voff = v ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.ldx) * 4u + b_colb[i] : OOB;
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0));
       }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf) {        // transpose: channel rows, pixel columns
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[buf][a_r + i * AR][a_c * 4]) = ra[i];
+    for (int i = 0; i < AI; ++i)
 #pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][b_r + i * BR][b_c * 4]) = rb[i];
+      for (int j = 0; j < 4; ++j) As[buf][a_row[i] + j][a_pix[i]] = ra[i][j];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bs[buf][b_row[i] + j][b_pix[i]] = rb[i][j];
   };
 
   f32x16 acc[MT][NT];
@@ -147,18 +154,22 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
   for (int s = 0; s < KT; ++s) {
     const int buf = s & 1;
     if (s + 1 < KT) load_stage(s + 1);
+    const float* Ab = &As[buf][wm * MT * 32 + lr][lh * 4];
+    const float* Bb = &Bs[buf][wn * NT * 32 + lr][lh * 4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float a[MT], b[NT];
+    for (int g = 0; g < 4; ++g) {          // lanes 0-31 take pixels 8g..8g+3, lanes 32-63 pixels 8g+4..8g+7
+      f32x4 a[MT], b[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = As[buf][2 * k + lh][(wm * MT + i) * 32 + lr];
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * WLDS + g * 8);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = Bs[buf][2 * k + lh][(wn * NT + j) * 32 + lr];
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * WLDS + g * 8);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
     }
     if (s + 1 < KT) store_stage(buf ^ 1);
     __syncthreads();
@@ -216,9 +227,9 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
   if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
   const int TM = (Cout % 128 == 0) ? 128 : 64;
   const int TN = (Cin % 128 == 0) ? 128 : 64;
-  if (splits <= 0) {   // aim for >= ~512 workgroups, keep >= 256 pixels per split
+  if (splits <= 0) {   // ~one full round of 2 workgroups per CU, >= 512 pixels per split
     long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
-    splits = (int)((512 + tiles / 2) / tiles);      // ~one full round of 2 workgroups per CU
+    splits = (int)((512 + tiles / 2) / tiles);
     int maxs = (p.P + 511) / 512;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
