@@ -227,12 +227,19 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
   if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
   const int TM = (Cout % 128 == 0) ? 128 : 64;
   const int TN = (Cin % 128 == 0) ? 128 : 64;
-  if (splits <= 0) {   // ~one full round of 2 workgroups per CU, >= 512 pixels per split
-    long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
-    splits = (int)((512 + tiles / 2) / tiles);
-    int maxs = (p.P + 511) / 512;
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
+  if (splits <= 0) {
+    // Fill the resident slots (256 CUs x 2 workgroups, 4 for the 64x64 tile) in WHOLE rounds: tiles * splits must
+    // not exceed a multiple of the slot count by a few workgroups (a 513th workgroup costs a full extra round).
+    const long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
+    const long slots = 256L * ((TM == 64 && TN == 64) ? 4 : 2);
+    const int maxs = (p.P + 511) / 512;                     // keep >= 512 pixels per split
+    if (tiles >= slots) {
+      splits = 1;
+    } else {
+      splits = (int)(slots / tiles);
+      if (splits > maxs) splits = maxs;
+      if (splits < 1) splits = 1;
+    }
   }
   int chunk = ((p.P + splits - 1) / splits + 31) & ~31;
   splits = (p.P + chunk - 1) / chunk;
