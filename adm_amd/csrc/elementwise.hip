@@ -297,6 +297,42 @@ __global__ void sampler_step_kernel(double* __restrict__ x, const float* __restr
   }
 }
 
+// Stochastic reverse step (ddm_const.py:296-303, 410-414 / ddm_const_2.py:185-197, 324-328): per image b
+//   x0 = x - C t - g(t) eps_model ; [clamp] ; C' = -x0 ;
+//   const  : mean = x + C'(t-s) - C' t - s/sqrt(t) eps_model,     sigma = sqrt(s (t-s) / t)
+//   const_2: mean = x - C' s - (2 s t - s^2)/t eps_model,         sigma = sqrt(2 s t - s^2) (t-s)/t
+//   x <- mean + sigma * z        (z = injected N(0,1) draw, fp64 state)
+__global__ void sampler_step_stochastic_kernel(double* __restrict__ x, const float* __restrict__ cp,
+                                               const float* __restrict__ np_, const double* __restrict__ z,
+                                               const double* __restrict__ t, const double* __restrict__ s_,
+                                               int schedule, int clip_x0, double scale_input, int last, long n,
+                                               long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / n;
+    const double tt = t[b], s = s_[b];
+    const double c = (double)cp[i], e = (double)np_[i], xv = x[i];
+    const double g = schedule == 0 ? sqrt(tt) : tt;
+    double x0 = xv - c * tt - g * e;
+    if (clip_x0) x0 = fmin(fmax(x0, -scale_input), scale_input);
+    const double c2 = -x0;
+    double mean, sigma;
+    if (schedule == 0) {
+      mean = xv + c2 * (tt - s) - c2 * tt - s / sqrt(tt) * e;
+      sigma = sqrt(s * (tt - s) / tt);
+    } else {
+      mean = xv - c2 * s - (2.0 * s * tt - s * s) / tt * e;
+      sigma = sqrt(2.0 * s * tt - s * s) * (tt - s) / tt;
+    }
+    double xn = mean + sigma * z[i];
+    if (last) {
+      xn = fmin(fmax(xn, -scale_input), scale_input);
+      if (scale_input != 1.0) xn = xn / scale_input;
+      xn = (xn + 1.0) * 0.5;
+    }
+    x[i] = xn;
+  }
+}
+
 // ---------------------------------------------------------------- optimiser
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, double* __restrict__ out, long n) {
   __shared__ double red[4];
@@ -480,6 +516,16 @@ extern "C" int adm_sampler_step(double* x, const float* c_pred, const float* n_p
   double gc = schedule == 0 ? sqrt(t_cur) : t_cur, gn = schedule == 0 ? sqrt(t_next) : t_next;
   hipLaunchKernelGGL(sampler_step_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, c_pred, n_pred, t_cur, t_next, gc,
                      gn, clip_x0, scale_input, last, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_sampler_step_stochastic(double* x, const float* c_pred, const float* n_pred, const double* z,
+                                           const double* t, const double* s, int schedule, int clip_x0,
+                                           double scale_input, int last, int B, long n, hipStream_t stream) {
+  if (!x || !c_pred || !n_pred || !z || !t || !s || B <= 0 || n <= 0 || (schedule != 0 && schedule != 1)) return ADM_EINVAL;
+  hipLaunchKernelGGL(sampler_step_stochastic_kernel, dim3(ew_grid((long)B * n)), dim3(256), 0, stream, x, c_pred, n_pred,
+                     z, t, s, schedule, clip_x0, scale_input, last, n, (long)B * n);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -46,6 +46,7 @@ _SIGS = {
     "adm_q_sample": [P, P, P, P, I, L, I, P],
     "adm_ddm_loss": [P, P, P, P, P, P, P, P, F, I, L, P],
     "adm_sampler_step": [P, P, P, D, D, I, I, D, I, L, P],
+    "adm_sampler_step_stochastic": [P, P, P, P, P, P, I, I, D, I, I, L, P],
     "adm_sumsq": [P, P, L, P],
     "adm_adamw_step": [P, P, P, P, P, P, L, F, F, F, F, F, F, I, F, F, P],
 }

@@ -548,3 +548,12 @@ def sampler_step(x64, c_pred, n_pred, t_cur: float, t_next: float, schedule: int
     call("adm_sampler_step", ptr(x64), ptr(_chk(c_pred, "C")), ptr(_chk(n_pred, "noise")), float(t_cur), float(t_next),
          schedule, int(clip_x0), float(scale_input), int(last), x64.numel())
     return x64
+
+
+def sampler_step_stochastic(x64, c_pred, n_pred, z64, t64, s64, schedule: int, clip_x0: bool, scale_input: float,
+                            last: bool):
+    """In-place stochastic reverse step on the fp64 state (per-image t, s as fp64 device vectors)."""
+    B = x64.shape[0]
+    call("adm_sampler_step_stochastic", ptr(x64), ptr(_chk(c_pred, "C")), ptr(_chk(n_pred, "noise")), ptr(z64), ptr(t64),
+         ptr(s64), schedule, int(clip_x0), float(scale_input), int(last), B, x64.numel() // B)
+    return x64

@@ -154,6 +154,13 @@ int adm_ddm_loss(const float* c_pred, const float* n_pred, const float* x0, cons
 int adm_sampler_step(double* x, const float* c_pred, const float* n_pred, double t_cur, double t_next, int schedule,
                      int clip_x0, double scale_input, int last, long n, hipStream_t stream);
 
+/* One stochastic sampler update in fp64 (ddm_const.py:296-303, 410-414 / ddm_const_2.py:185-197, 324-328):
+ * x0 = x - C t - g(t) eps; [clamp]; C' = -x0; x <- mean(x, C', eps, t, s) + sigma(t, s) z, per-image t[B], s[B];
+ * z = the N(0,1) draw (device fp64).  last: final clamp, /scale, (x+1)/2. */
+int adm_sampler_step_stochastic(double* x, const float* c_pred, const float* n_pred, const double* z, const double* t,
+                                const double* s, int schedule, int clip_x0, double scale_input, int last, int B, long n,
+                                hipStream_t stream);
+
 /* ---------------- optimiser (train_uncond_dpm.py:292-310, ddm/ema.py:158-188) ---------------- */
 
 /* sumsq[0] += sum g^2 */

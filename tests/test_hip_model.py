@@ -174,6 +174,24 @@ def test_deterministic_sampler_vs_golden(gpu, golden_dir, sched):
         close(simg, g7["const_2.stochastic_img"])
 
 
+def test_stochastic_sampler_const_vs_oracle(gpu):
+    """sample_fn_s for the sqrt(t) schedule (ddm_const.py:380-422; that module cannot be imported, so the pin is
+    the oracle restatement run on the CPU with the same injected draws)."""
+    dpm, cfg, sd, eps, smin = make_ddpm("const", gpu)
+    dpm.eval()
+    draws = [fill.hash_tensor((2, 3, 32, 32), f"s{k}", 1.7, torch.float64) for k in range(11)]
+    img = dpm.sample_fn_s((2, 3, 32, 32), x_T=draws[0].to(gpu), epsilons=draws[1:])
+    assert img.dtype == torch.float64 and float(img.min()) >= 0 and float(img.max()) <= 1
+    with torch.no_grad():
+        want = ddm_ref.sample_fn_s("const", lambda x, tt: unet_ref.edm_precond(sd, cfg, x, tt), draws[0], draws[1:], 10,
+                                   smin, 1.0)
+    close(img, want)
+    dpm.cfg["sample_type"] = "stochastic"
+    torch.manual_seed(3)
+    a = dpm.sample(batch_size=2)
+    assert a.shape == (2, 3, 32, 32) and float(a.min()) >= 0 and float(a.max()) <= 1
+
+
 def test_training_mode_dropout_runs_and_is_seeded(gpu):
     m, cfg, _ = build_unet("uncond_unet", gpu, dropout=0.1)
     m.train()
