@@ -42,19 +42,17 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int lr = lane & 31, lh = lane >> 5;
+  // Workgroup -> tile map, XCD-aware: consecutive block ids are dealt round-robin over the 8 XCDs, each with its own
+  // L2.  Give every XCD a CONTIGUOUS chunk of the tile list (bijective remap) and order the list m-fastest inside an
+  // n-tile, so the workgroups resident on one XCD at a time share the same weight slice (BN x K floats, fits the 4 MB
+  // L2) and neighbouring pixel tiles (shared halo rows).  Placement only affects speed / traffic, never results.
   int bid = blockIdx.x;
-#ifdef ADM_EXP_XCD
-  {   // XCD-aware remap (bijective): blocks dealt round-robin over 8 XCDs -> give each XCD a contiguous chunk
+  {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-#endif
-#ifdef ADM_EXP_TMMAJOR
   const int tilesM = gridDim.x / p.tilesN;
   const int tm = bid % tilesM, tn = bid / tilesM;
-#else
-  const int tn = bid % p.tilesN, tm = bid / p.tilesN;
-#endif
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- loader state: each thread owns float4 column c4 of rows r0 + 32 i ----
@@ -161,43 +159,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
 
   for (int s = 0; s < KT; ++s) {
     const int buf = s & 1;
-#ifndef ADM_EXP_NOLOAD
     if (s + 1 < KT) load_stage();
-#endif
     const float* Ab = As + buf * BM * LDSS + (wm * MT * 32 + lr) * LDSS + lh * 4;
     const float* Bb = Bs + buf * BN * LDSS + (wn * NT * 32 + lr) * LDSS + lh * 4;
-#ifdef ADM_EXP_PREFETCH
-    {
-      f32x4 a[2][MT], b[2][NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cur = g & 1, nxt = cur ^ 1;
-        if (g < 3) {
-#pragma unroll
-          for (int i = 0; i < MT; ++i) a[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS + (g + 1) * 8);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) b[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS + (g + 1) * 8);
-        }
-#ifdef ADM_EXP_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][k], b[cur][j][k], acc[i][j], 0, 0, 0);
-#ifdef ADM_EXP_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-      }
-    }
-#else
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 a[MT], b[NT];
@@ -205,9 +169,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
       for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS + g * 8);
 #pragma unroll
       for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS + g * 8);
-#ifdef ADM_EXP_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -215,17 +176,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
-#ifdef ADM_EXP_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
-#endif
-#ifndef ADM_EXP_NOLOAD
     if (s + 1 < KT) store_stage(buf ^ 1);
-#endif
-#ifndef ADM_EXP_NOBARRIER
     __syncthreads();
-#endif
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5) ----
