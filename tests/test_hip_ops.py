@@ -52,7 +52,8 @@ def pad_c(t, c):
 @pytest.mark.parametrize("cin,cout,H,ks,up,tile", [
     (32, 64, 8, 3, False, -1), (64, 96, 16, 3, False, 1), (64, 128, 16, 3, False, 0), (96, 64, 8, 1, False, 2),
     (64, 32, 8, 3, False, 3), (64, 64, 4, 3, True, -1), (192, 192, 32, 3, False, -1), (3, 64, 16, 3, False, -1),
-    (64, 3, 16, 3, False, -1), (384, 1, 4, 1, False, -1)])
+    (64, 3, 16, 3, False, -1), (384, 1, 4, 1, False, -1),
+    (32, 64, 12, 3, False, -1), (32, 32, 64, 3, False, -1), (64, 32, 6, 3, True, -1)])   # non-power-of-two / W > 32: generic paths
 def test_conv_forward_backward(ops, cin, cout, H, ks, up, tile):
     B = 3
     x = fill.hash_tensor((B, cin, H, H), f"cx{cin}{cout}", 1.0)
