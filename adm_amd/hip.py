@@ -21,6 +21,9 @@ _SIGS = {
     "adm_version": [],
     "adm_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_f32_to_bf16": [P, P, L, P],
     "adm_pack_weight": [P, P, P, I, I, I, I, I, I, P],
     "adm_unpack_wgrad": [P, P, I, I, I, I, I, I, I, P],
     "adm_permute_vec": [P, P, I, I, I, I, P],

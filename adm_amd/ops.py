@@ -59,7 +59,31 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 # packed-weight cache
 # ------------------------------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("key", "fwd", "bwd", "bias")
+    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16")
+
+
+# Contraction precision of the conv / Linear kernels: "f32" (default: exact fp32 MFMA) or "bf16" (BASELINE
+# configs[2]: bf16 MFMA operands, fp32 accumulation and storage).  Opt-in only; see set_compute_precision().
+COMPUTE = "f32"
+
+
+def set_compute_precision(mode: str):
+    global COMPUTE
+    if mode not in ("f32", "bf16"):
+        raise ValueError("compute precision must be 'f32' or 'bf16'")
+    COMPUTE = mode
+
+
+def _bf16_operand(ent: "_Packed", which: str) -> torch.Tensor:
+    """bf16 copy of a packed weight operand, built on first use per packed entry."""
+    name = which + "16"
+    t = getattr(ent, name, None)
+    if t is None:
+        src = getattr(ent, which)
+        t = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+        call("adm_f32_to_bf16", ptr(src), ptr(t), src.numel())
+        setattr(ent, name, t)
+    return t
 
 
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
@@ -80,6 +104,7 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     w = _chk(weight.detach(), "weight")
     ent = _Packed()
     ent.key = key
+    ent.fwd16 = ent.bwd16 = None
     ent.fwd = _new((cop, ks * ks * cip), w)
     ent.bwd = _new((cip, ks * ks * cop), w)
     call("adm_pack_weight", ptr(w), ptr(ent.fwd), ptr(ent.bwd), co, ci, ks, cop, cip, int(qkv))
@@ -142,17 +167,22 @@ class _Conv(torch.autograd.Function):
             res = _chk(residual, "residual")
             if tuple(res.shape) != tuple(y.shape):
                 raise RuntimeError(f"residual shape {tuple(res.shape)} != output {tuple(y.shape)}")
+        bf16 = COMPUTE == "bf16"
         with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"fwd M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
-            call("adm_conv_fwd", ptr(x), ptr(pk.fwd), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop,
-                 cop, cop, ks, int(up), tile)
+            if bf16 and cip % 64 == 0:
+                call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
+                     Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
+            else:
+                call("adm_conv_fwd", ptr(x), ptr(pk.fwd), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop,
+                     cop, cop, ks, int(up), tile)
         ctx.save_for_backward(x, weight, bias)
-        ctx.meta = (ks, up, qkv, residual is not None)
+        ctx.meta = (ks, up, qkv, residual is not None, bf16)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        ks, up, qkv, has_res = ctx.meta
+        ks, up, qkv, has_res, bf16 = ctx.meta
         dy = _chk(dy, "dy")
         B, Ho, Wo, cop = dy.shape
         co, ci = weight.shape[0], weight.shape[1]
@@ -162,8 +192,12 @@ class _Conv(torch.autograd.Function):
             pk = packed(weight, bias, ks, qkv)
             dxf = _new((B, Ho, Wo, cip), dy)
             with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"dgrad M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
-                call("adm_conv_fwd", ptr(dy), ptr(pk.bwd), None, None, ptr(dxf), B, Ho, Wo, cop, cop, cip, cip, cip,
-                     cip, ks, 0, -1)
+                if bf16 and cop % 64 == 0:
+                    call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
+                         cop, cop, cip, cip, cip, cip, ks, 0, -1)
+                else:
+                    call("adm_conv_fwd", ptr(dy), ptr(pk.bwd), None, None, ptr(dxf), B, Ho, Wo, cop, cop, cip, cip, cip,
+                         cip, ks, 0, -1)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
                 call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)
@@ -172,7 +206,8 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dwp = _new((cop, ks * ks * cip), dy)
             with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"wgrad P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
-                call("adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+                call("adm_conv_wgrad_bf16" if bf16 else "adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip,
+                     cop, cop, ks, int(up), 0)
             sink = _direct_grad(weight)
             if sink is not None:
                 call("adm_unpack_wgrad", ptr(dwp), ptr(sink), co, ci, ks, cop, cip, int(qkv), 1)

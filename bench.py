@@ -23,6 +23,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: ~2.5 PFLOP/s dense bf16
 
 
 def log(msg):
@@ -51,6 +52,9 @@ def parse():
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="run warmup+steps only (for rocprofv3)")
     ap.add_argument("--small", action="store_true", help="reduced-width model (debug only; result marked invalid)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="contraction precision of conv/Linear: f32 = BASELINE configs[1] (default, exact fp32 MFMA); "
+                         "bf16 = configs[2] mode (bf16 MFMA operands, fp32 accumulate/storage)")
     return ap.parse_args()
 
 
@@ -136,6 +140,7 @@ def main():
     from adm_amd import hip, ops
     from adm_amd.optim import BucketedGradReducer, FlatParams, FusedAdamWEMA, ema_decay_at, lr_lambda
     hip.lib()
+    ops.set_compute_precision(args.dtype)
 
     dpm = build_model(dev, args.small)
     dpm.train()
@@ -218,15 +223,19 @@ def main():
             traffic_src = "profiles/" + pmc
         except Exception:
             pass
-        roof = {"kernel": "igemm_f32_kernel (conv/linear forward + data-gradient)", "bound": "mfma",
-                "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        if args.dtype != "f32":
+            traffic, traffic_src = None, None       # the committed PMC passes are of the fp32 kernels
+        roof = {"kernel": ("igemm_f32_kernel" if args.dtype == "f32" else "igemm_bf16_kernel") +
+                          " (conv/linear forward + data-gradient)", "bound": "mfma",
+                "achieved": round(fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(fl / ms / 1e9 / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes/launch (L2-miss side: HBM + Infinity Cache)", "traffic_source": traffic_src,
                 "algorithmic_flops_per_launch": round(fl / max(n, 1)), "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "ms_per_step_in_kernel": round(ms, 2)}
         if "wgrad" in by:
             fl2, ms2, n2 = by["wgrad"]
             roof["wgrad"] = {"kernel": "wgrad_f32_kernel", "achieved": round(fl2 / ms2 / 1e9, 2),
-                             "frac": round(fl2 / ms2 / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": n2,
+                             "frac": round(fl2 / ms2 / 1e9 / peak, 4), "launches_per_step": n2,
                              "ms_per_step_in_kernel": round(ms2, 2)}
         if "attn" in by:
             fl3, ms3, n3 = by["attn"]
@@ -254,10 +263,11 @@ def main():
         out = {"metric": "train images/sec (CIFAR-10 32x32 uncond DDM UNet, 1 optimizer step/iter) + 10-step sample images/sec",
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": args.dtype, "data": "synthetic",
                "sample_images_per_sec": None if sample_ips is None else round(sample_ips, 2),
-               "config": {"workload": "BASELINE configs[1]: CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), "
-                                      f"bs={B}/GPU fp32, ddm_const schedule, dropout 0.1, loss_simple (LPIPS term needs "
+               "config": {"workload": ("BASELINE configs[1]" if args.dtype == "f32" else "BASELINE configs[2] (per-GPU share)") +
+                                      ": CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), "
+                                      f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, ddm_const schedule, dropout 0.1, loss_simple (LPIPS term needs "
                                       "unfetchable VGG16 weights), clip 1.0 + AdamW + EMA(every 8)",
                           "global_batch": world * B, "image": "3x32x32", "sampling_timesteps": 10,
                           "parallelism": f"dp{world}", "valid": not args.small},

@@ -46,6 +46,17 @@ int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float
 int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
                    int Cout, int lddy, int ks, int up, int splits, hipStream_t stream);
 
+/* ---- reduced-precision option (BASELINE.json configs[2], "bf16"): same contracts as adm_conv_fwd / adm_conv_wgrad,
+ * tensors stay fp32 in HBM, the contraction runs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 on their way
+ * into LDS, fp32 accumulation).  wp16 = the adm_pack_weight layouts converted with adm_f32_to_bf16.  Cin % 64 == 0
+ * for adm_conv_fwd_bf16.  Never selected implicitly: the host opts in (adm_amd.ops.set_compute_precision). */
+int adm_conv_fwd_bf16(const float* x, const unsigned short* wp16, const float* bias, const float* res, float* y,
+                      int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks, int up,
+                      int tile, hipStream_t stream);
+int adm_conv_wgrad_bf16(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx, int Cout,
+                        int lddy, int ks, int up, int splits, hipStream_t stream);
+int adm_f32_to_bf16(const float* src, unsigned short* dst, long n, hipStream_t stream);
+
 /* OIHW [Co][Ci][ks][ks] (the reference's parameter layout, uncond_unet.py:85) ->
  *   wp_fwd [Co_pad][ks*ks][Ci_pad]            (B operand of adm_conv_fwd)
  *   wp_bwd [Ci_pad][ks*ks flipped][Co_pad]    (B operand of adm_conv_fwd computing dL/dx)

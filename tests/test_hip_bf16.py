@@ -1,0 +1,101 @@
+"""GPU: the opt-in bf16-MFMA contraction mode (BASELINE configs[2]).  No reference counterpart exists (every
+reference config runs fp32), so the bar is the build's own: (1) against a torch reference whose OPERANDS are
+rounded to bf16 the kernels must agree to fp32-accumulation accuracy (rtol 2e-4): that isolates the kernel from
+the rounding; (2) against the un-rounded fp32 reference the error must stay at bf16 level (2e-2 of the output
+scale); (3) end to end on the reduced UNet: <= 3e-2 of the output scale for outputs, cosine >= 0.999 for the
+flattened gradient."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fill, unet_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ops_bf16():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import hip, ops
+    hip.lib()
+    ops.set_compute_precision("bf16")
+    yield ops
+    ops.set_compute_precision("f32")
+
+
+def r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("cin,cout,H,ks,up", [(64, 128, 16, 3, False), (192, 192, 32, 3, False), (128, 64, 8, 1, False),
+                                              (64, 64, 8, 3, True), (384, 96, 12, 3, False), (64, 3, 16, 3, False)])
+def test_conv_bf16_forward_backward(ops_bf16, cin, cout, H, ks, up):
+    ops = ops_bf16
+    B = 3
+    x = fill.hash_tensor((B, cin, H, H), f"bx{cin}{cout}", 1.0)
+    w = fill.hash_tensor((cout, cin, ks, ks), f"bw{cin}{cout}", 1.0 / math.sqrt(cin * ks * ks))
+    b = fill.hash_tensor((cout,), f"bb{cin}{cout}", 0.5)
+    Ho = 2 * H if up else H
+    gy = fill.hash_tensor((B, cout, Ho, Ho), f"bg{cin}{cout}", 1.0)
+    cop = ops.ceil32(cout)
+    pad = lambda t, c: torch.cat([t, torch.zeros(t.shape[0], c - t.shape[1], *t.shape[2:])], 1) if c > t.shape[1] else t
+    xd = pad(x, ops.ceil32(cin)).permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, None, up=up)
+    (y * pad(gy, cop).permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    yh = y.detach().cpu().permute(0, 3, 1, 2)[:, :cout]
+
+    def ref(xx, ww, gg):
+        xr, wr, br = xx.clone().requires_grad_(True), ww.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+        yr = F.conv2d(xin, wr, br, padding=ks // 2)
+        return yr, xr, wr
+
+    # (1) operands rounded exactly as the kernel rounds them.  dgrad rounds dy and w; wgrad rounds dy and x.
+    yr, xr, wr = ref(r16(x), r16(w), gy)
+    torch.testing.assert_close(yh, yr.detach(), rtol=2e-4, atol=2e-4 * float(yr.detach().abs().max()))
+    yr.backward(r16(gy))
+    if cop % 64 == 0:       # dgrad ran in bf16 (else the fp32 kernel handled it)
+        torch.testing.assert_close(xd.grad.cpu().permute(0, 3, 1, 2)[:, :cin], xr.grad, rtol=2e-4,
+                                   atol=2e-4 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=2e-4, atol=3e-4 * float(wr.grad.abs().max()))
+    # (2) versus full fp32: bf16-level error only
+    y32, x32, w32 = ref(x, w, gy)
+    y32.backward(gy)
+    assert float((yh - y32.detach()).abs().max()) <= 2e-2 * float(y32.abs().max())
+    assert float((wd.grad.cpu() - w32.grad).abs().max()) <= 2e-2 * float(w32.grad.abs().max())
+    torch.testing.assert_close(bd.grad.cpu(), gy.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4 * float(gy.sum(dim=(0, 2, 3)).abs().max()))
+
+
+def test_unet_bf16_vs_f32_end_to_end(ops_bf16):
+    ops = ops_bf16
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    cfg = unet_ref.default_cfg(variant="uncond_unet", model_channels=64, num_blocks=1, dropout=0.0)
+    kw = {k: cfg[k] for k in ("model_channels", "channel_mult", "channel_mult_emb", "num_blocks", "attn_resolutions",
+                              "dropout", "augment_dim")}
+    m = EDMPrecond(img_resolution=32, img_channels=3, **kw)
+    m.load_state_dict(fill.filled_state_dict(unet_ref.param_shapes(cfg)))
+    m = m.cuda().eval()
+    x = fill.hash_tensor((2, 3, 32, 32), "x", 1.0).cuda()
+    sigma = torch.tensor([0.05, 0.7]).cuda()
+    gx = fill.hash_tensor((2, 3, 32, 32), "gx", 1.0).cuda()
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        dx, dy = m(x, sigma)
+        ((dx * gx).sum() + (dy * gx).sum()).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+        return dx.detach(), dy.detach(), g
+
+    a16 = run()
+    ops.set_compute_precision("f32")
+    a32 = run()
+    for u, v in zip(a16[:2], a32[:2]):
+        assert float((u - v).abs().max()) <= 3e-2 * float(v.abs().max())
+        assert float((u - v).abs().max()) > 0          # the bf16 path really ran
+    cos = float(torch.dot(a16[2].double(), a32[2].double()) / (a16[2].double().norm() * a32[2].double().norm()))
+    assert cos >= 0.999, cos
