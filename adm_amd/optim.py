@@ -122,6 +122,7 @@ class BucketedGradReducer:
     def finish(self):
         """Call after backward: launches any bucket whose hooks did not all fire (parameters without a
         gradient this step) and joins the side stream."""
+        ops.join_side_streams()
         if self.active and self.enabled:
             for b in range(len(self.buckets)):
                 if self.pending[b] != self.buckets[b][2]:
@@ -151,6 +152,7 @@ class FusedAdamWEMA:
         """grad_scale multiplies the raw gradient buffer (1/world after a SUM all-reduce, 1/accum for
         gradient accumulation).  ema_decay None = leave the EMA untouched this step; 0 = copy."""
         f = self.flat
+        ops.join_side_streams()        # weight gradients are produced on a side stream (ops.SIDE_WGRAD)
         self.step_count += 1
         self.sumsq.zero_()
         call("adm_sumsq", ptr(f.grad), ptr(self.sumsq), f.numel)
