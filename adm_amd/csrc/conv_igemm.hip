@@ -26,6 +26,7 @@ namespace {
 struct IgemmP {
   const float* x; const float* w; const float* bias; const float* res; float* y;
   int M, N, H, W, Hin, Win, Cin, ldx, K, ldy, ldr, ks, up, wrows, tilesN, xbytes, wbytes;
+  int splitk, kt_per_split; float* ws;     // split-K: partial tiles go to ws[z][M][N], summed by splitk_reduce_kernel
 };
 
 constexpr int LDSS = 36;   // floats per LDS row (32 + 4 pad)
@@ -99,7 +100,13 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
     a_voff[i] = OOB;
   }
   const int cchunks = p.Cin >> 5;
-  const int KT = p.ks * p.ks * cchunks;
+  const int KTall = p.ks * p.ks * cchunks;
+  const int s_begin = (p.splitk > 1) ? (int)blockIdx.y * p.kt_per_split : 0;
+  const int KT = (p.splitk > 1) ? min(p.kt_per_split, KTall - s_begin) : KTall;     // stages of THIS workgroup
+  if (p.splitk > 1) {          // raw partial tile, no bias / residual: those are applied by the reduction
+    p.y = p.ws + (long)blockIdx.y * p.M * p.N;
+    p.ldy = p.N; p.bias = nullptr; p.res = nullptr;
+  }
   unsigned b_voff[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
@@ -108,10 +115,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   }
 
   f32x4 ra[AI], rb[BI];
-  int ld_tap = 0, ld_cc = 0;       // (tap, channel chunk) of the NEXT stage to load: no division per stage
+  int ld_tap = s_begin / cchunks, ld_cc = s_begin - ld_tap * cchunks;   // (tap, channel chunk) of the NEXT stage to load
+  bool a_fresh = true;             // a split-K range may start in the middle of a tap
   auto load_stage = [&]() {
     const int tap = ld_tap;
-    if (ld_cc == 0) {              // new tap: rebuild the per-row offsets (wave-uniform branch, every Cin/32 steps)
+    if (ld_cc == 0 || a_fresh) {   // new tap: rebuild the per-row offsets (wave-uniform branch, every Cin/32 steps)
+      a_fresh = false;
       int dy = 0, dx = 0;
       if (p.ks == 3) { dy = tap / 3 - pad; dx = tap - (tap / 3) * 3 - pad; }
 #pragma unroll
@@ -240,7 +249,7 @@ int launch_igemm_up(IgemmP p, hipStream_t st) {
   }
   p.tilesN = adm_cdiv(p.N, BN);
   long grid = (long)adm_cdiv(p.M, BM) * p.tilesN;
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, UP>), dim3((unsigned)grid), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, UP>), dim3((unsigned)grid, p.splitk > 1 ? p.splitk : 1), dim3(256), smem, st, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -250,7 +259,41 @@ int launch_igemm(IgemmP p, hipStream_t st) {
   return p.up ? launch_igemm_up<BM, BN, WM, WN, true>(p, st) : launch_igemm_up<BM, BN, WM, WN, false>(p, st);
 }
 
+// y[m][n] = sum_z ws[z][m][n] + bias[n] + res[m][n]   (fixed summation order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                     const float* __restrict__ res, float* __restrict__ y, long M, int N, int ldy,
+                                     int ldr, int splitk) {
+  const int N4 = N >> 2;
+  const long total = M * N4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / N4;
+    const int n = (int)(i - m * N4) * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+    for (int z = 1; z < splitk; ++z) a += *reinterpret_cast<const f32x4*>(ws + ((long)z * M + m) * N + n);
+    if (bias) a += *reinterpret_cast<const f32x4*>(bias + n);
+    if (res) a += *reinterpret_cast<const f32x4*>(res + m * ldr + n);
+    *reinterpret_cast<f32x4*>(y + m * ldy + n) = a;
+  }
+}
+
+int splitk_plan(long M, int N, int K) {
+  // Only the small-M layers (4x4 resolution, the embedding Linears): too few 64x64 tiles to fill 256 CUs.
+  const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  const int KT = K / 32;
+  if (tiles > 256 || KT < 16 || (N & 3)) return 1;
+  long s = 1024 / tiles;
+  if (s > 8) s = 8;
+  if (s > KT / 8) s = KT / 8;
+  return s < 2 ? 1 : (int)s;
+}
+
 }  // namespace
+
+extern "C" int adm_conv_splitk(int M, int N, int K) { return splitk_plan(M, N, K); }
+
+extern "C" int adm_conv_fwd_ws(const float* x, const float* wp, const float* bias, const float* res, float* y,
+                               float* ws, long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows,
+                               int ldy, int ldr, int ks, int up, hipStream_t stream);
 
 extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float* res, float* y,
                             int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
@@ -264,7 +307,7 @@ extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, 
   p.M = B * H * W; p.N = N; p.H = H; p.W = W;
   p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.K = ks * ks * Cin; p.ldy = ldy; p.ldr = ldr; p.ks = ks; p.up = up; p.wrows = wrows;
-  p.tilesN = 0;
+  p.tilesN = 0; p.splitk = 1; p.kt_per_split = 0; p.ws = nullptr;
   const long xb = (long)B * p.Hin * p.Win * ldx * 4, wb = (long)wrows * p.K * 4;
   if (xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;     // 32-bit buffer offsets; 0x80000000 must stay out of range
   p.xbytes = (int)xb; p.wbytes = (int)wb;
@@ -292,4 +335,42 @@ extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, 
     case 3: return launch_igemm<128, 32, 4, 1>(p, stream);
     default: return ADM_EINVAL;
   }
+}
+
+// Same as adm_conv_fwd with a caller-provided workspace: when adm_conv_splitk(M, N, K) > 1 the K range is split
+// over gridDim.y, partial tiles go to ws[splitk][M][N] and a second launch sums them (+ bias, + residual) in a
+// fixed order, so the result stays deterministic.  ws_floats >= splitk * M * N.
+extern "C" int adm_conv_fwd_ws(const float* x, const float* wp, const float* bias, const float* res, float* y,
+                               float* ws, long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows,
+                               int ldy, int ldr, int ks, int up, hipStream_t stream) {
+  const long M = (long)B * H * W;
+  const int K = ks * ks * Cin;
+  const int sk = (ws && (Cin & 31) == 0) ? splitk_plan(M, N, K) : 1;
+  if (sk <= 1 || ws_floats < (long)sk * M * N)
+    return adm_conv_fwd(x, wp, bias, res, y, B, H, W, Cin, ldx, N, wrows, ldy, ldr, ks, up, -1, stream);
+  if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
+  if ((ldx & 3) || (ks != 1 && ks != 3) || N <= 0 || wrows < N || (ldy & 3) || (ldr & 3)) return ADM_EINVAL;
+  if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)ws | (uintptr_t)y) & 15) return ADM_EINVAL;
+  IgemmP p;
+  p.x = x; p.w = wp; p.bias = bias; p.res = res; p.y = y;
+  p.M = (int)M; p.N = N; p.H = H; p.W = W;
+  p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
+  p.Cin = Cin; p.ldx = ldx; p.K = K; p.ldy = ldy; p.ldr = ldr; p.ks = ks; p.up = up; p.wrows = wrows;
+  p.tilesN = 0;
+  const long xb = (long)B * p.Hin * p.Win * ldx * 4, wb = (long)wrows * p.K * 4;
+  if (xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;
+  p.xbytes = (int)xb; p.wbytes = (int)wb;
+  const int KT = K / 32;
+  p.splitk = sk; p.kt_per_split = (KT + sk - 1) / sk; p.ws = ws;
+  p.splitk = (KT + p.kt_per_split - 1) / p.kt_per_split;
+  int rc = launch_igemm<64, 64, 2, 2>(p, stream);
+  if (rc != ADM_OK) return rc;
+  const long total = M * (N / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, bias, res, y, M, N, ldy, ldr,
+                     p.splitk);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
 }

@@ -232,7 +232,7 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
     // not exceed a multiple of the slot count by a few workgroups (a 513th workgroup costs a full extra round).
     const long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
     const long slots = 256L * ((TM == 64 && TN == 64) ? 4 : 2);
-    const int maxs = (p.P + 511) / 512;                     // keep >= 512 pixels per split
+    const int maxs = (p.P + 127) / 128;                     // keep >= 128 pixels (4 K-steps) per split
     if (tiles >= slots) {
       splits = 1;
     } else {

@@ -20,6 +20,8 @@ P, I, L, F, D, U = c_void_p, c_int, c_long, c_float, c_double, c_uint64
 _SIGS = {
     "adm_version": [],
     "adm_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_splitk": [I, I, I],
+    "adm_conv_fwd_ws": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],

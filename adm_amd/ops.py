@@ -185,6 +185,19 @@ def _queue_join_at_end_of_backward():
 # ------------------------------------------------------------------------------------------------
 # convolution / linear
 # ------------------------------------------------------------------------------------------------
+def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile):
+    """fp32 implicit GEMM; small-M problems get the deterministic split-K path (workspace + fixed-order reduce)."""
+    if tile < 0:
+        sk = hip.lib().adm_conv_splitk(B * Ho * Wo, n_p, ks * ks * cin_p)
+        if sk > 1:
+            ws = _new((sk * B * Ho * Wo * n_p,), x)
+            call("adm_conv_fwd_ws", ptr(x), ptr(wp), ptr(bias), ptr(res), ptr(y), ptr(ws), ws.numel(), B, Ho, Wo, cin_p,
+                 cin_p, n_p, n_p, n_p, n_p, ks, up)
+            return
+    call("adm_conv_fwd", ptr(x), ptr(wp), ptr(bias), ptr(res), ptr(y), B, Ho, Wo, cin_p, cin_p, n_p, n_p, n_p, n_p, ks,
+         up, tile)
+
+
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, ks, up, qkv, tile):
@@ -208,8 +221,7 @@ class _Conv(torch.autograd.Function):
                 call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
                      Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
-                call("adm_conv_fwd", ptr(x), ptr(pk.fwd), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop,
-                     cop, cop, ks, int(up), tile)
+                _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile)
         ctx.save_for_backward(x, weight, bias)
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
         return y
@@ -274,8 +286,7 @@ class _Conv(torch.autograd.Function):
                     call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
                          cop, cop, cip, cip, cip, cip, ks, 0, -1)
                 else:
-                    call("adm_conv_fwd", ptr(dy), ptr(pk.bwd), None, None, ptr(dxf), B, Ho, Wo, cop, cop, cip, cip, cip,
-                         cip, ks, 0, -1)
+                    _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
                 call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)

@@ -40,6 +40,14 @@ int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float
                  int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                  int ks, int up, int tile, hipStream_t stream);
 
+/* Deterministic split-K for the small-M layers (4x4 resolution, embedding Linears): adm_conv_splitk(M, N, K) is the
+ * number of K slices the library would use (1 = none); adm_conv_fwd_ws is adm_conv_fwd with a workspace of at least
+ * splitk*M*N floats: partial tiles are written there and summed (+ bias, + res) in a fixed order by a second launch. */
+int adm_conv_splitk(int M, int N, int K);
+int adm_conv_fwd_ws(const float* x, const float* wp, const float* bias, const float* res, float* y, float* ws,
+                    long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks,
+                    int up, hipStream_t stream);
+
 /* dwp[Cout][ks*ks][Cin] = sum_pixels dy[p][co] * x[p+tap][ci]  (atomic fp32 accumulation over
  * `splits` pixel ranges; dwp is overwritten: the call zero-fills it when it splits).  The weight-gradient of the conv above
  * (autograd of F.conv2d in the reference).  Cout, Cin multiples of 32. */

@@ -53,7 +53,8 @@ def pad_c(t, c):
     (32, 64, 8, 3, False, -1), (64, 96, 16, 3, False, 1), (64, 128, 16, 3, False, 0), (96, 64, 8, 1, False, 2),
     (64, 32, 8, 3, False, 3), (64, 64, 4, 3, True, -1), (192, 192, 32, 3, False, -1), (3, 64, 16, 3, False, -1),
     (64, 3, 16, 3, False, -1), (384, 1, 4, 1, False, -1),
-    (32, 64, 12, 3, False, -1), (32, 32, 64, 3, False, -1), (64, 32, 6, 3, True, -1)])   # non-power-of-two / W > 32: generic paths
+    (32, 64, 12, 3, False, -1), (32, 32, 64, 3, False, -1), (64, 32, 6, 3, True, -1),   # non-power-of-two / W > 32: generic paths
+    (384, 384, 4, 3, False, -1), (768, 384, 4, 3, False, -1), (384, 96, 4, 1, False, -1)])   # small M: deterministic split-K
 def test_conv_forward_backward(ops, cin, cout, H, ks, up, tile):
     B = 3
     x = fill.hash_tensor((B, cin, H, H), f"cx{cin}{cout}", 1.0)
@@ -81,6 +82,19 @@ def test_conv_forward_backward(ops, cin, cout, H, ks, up, tile):
     close(wd.grad, wr.grad)
     close(bd.grad, br.grad)
     close(nchw(rd.grad)[:, :cout], rr.grad)
+
+
+def test_linear_split_k_is_deterministic(ops):
+    B, cin, cout = 7, 768, 768        # the embedding / affine Linear shape: split-K path
+    from adm_amd import hip
+    assert hip.lib().adm_conv_splitk(B, cout, cin) > 1
+    x = fill.hash_tensor((B, cin), "skx", 1.0)
+    w = fill.hash_tensor((cout, cin), "skw", 0.05)
+    b = fill.hash_tensor((cout,), "skb", 0.1)
+    r = fill.hash_tensor((B, cout), "skr", 1.0)
+    y = ops.linear(dev(x), dev(w), dev(b), dev(r))
+    close(y, x @ w.t() + b + r)
+    assert torch.equal(y, ops.linear(dev(x), dev(w), dev(b), dev(r)))
 
 
 def test_linear_and_qkv_permutation(ops):
