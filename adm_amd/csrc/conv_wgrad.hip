@@ -225,13 +225,15 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
   auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
   p.lw = ilog2(W); p.lh = ilog2(H);
   if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
-  const int TM = (Cout % 128 == 0) ? 128 : 64;
-  const int TN = (Cin % 128 == 0) ? 128 : 64;
+  // Cout = 192 / 576 (the 32x32-resolution blocks): a 192 x 64 tile (3 MFMA rows per wave, 73.7 KB of LDS like the
+  // 128 x 128 one) instead of 64-row tiles, which halve the operand reuse
+  const int TM = (Cout % 128 == 0) ? 128 : (Cout % 192 == 0) ? 192 : 64;
+  const int TN = (TM == 192) ? 64 : (Cin % 128 == 0) ? 128 : 64;
   if (splits <= 0) {
     // Fill the resident slots (256 CUs x 2 workgroups, 4 for the 64x64 tile) in WHOLE rounds: tiles * splits must
     // not exceed a multiple of the slot count by a few workgroups (a 513th workgroup costs a full extra round).
     const long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
-    const long slots = 256L * ((TM == 64 && TN == 64) ? 4 : 2);
+    const long slots = 256L * ((TM == 64 && TN == 64) ? 4 : 2);     // resident workgroups (LDS-limited)
     const int maxs = (p.P + 127) / 128;                     // keep >= 128 pixels (4 K-steps) per split
     if (tiles >= slots) {
       splits = 1;
@@ -248,6 +250,7 @@ extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B
   if (p.atomic &&
       hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * ks * ks * Cin, stream) != hipSuccess)
     return ADM_ELAUNCH;
+  if (TM == 192) return launch_wgrad<192, 64>(p, splits, stream);
   if (TM == 128 && TN == 128) return launch_wgrad<128, 128>(p, splits, stream);
   if (TM == 128 && TN == 64) return launch_wgrad<128, 64>(p, splits, stream);
   if (TM == 64 && TN == 128) return launch_wgrad<64, 128>(p, splits, stream);
