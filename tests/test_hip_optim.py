@@ -79,3 +79,35 @@ def test_direct_flat_gradients_and_fused_adamw():
     m2.load_state_dict(m.state_dict())
     y_chk = m2(fill.hash_tensor((2, 3, 32, 32), "x", 1.0).to(gpu), torch.tensor([0.05, 0.7], device=gpu))[0]
     torch.testing.assert_close(y_new, y_chk, rtol=1e-5, atol=1e-6)
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """End-to-end sanity of forward + backward + fused optimiser: overfit one batch with a reduced UNet (dropout on,
+    reference init incl. the zero-initialised conv1 / proj / map_augment)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd.ddm.ddm_const import DDPM
+    from adm_amd.optim import FlatParams, FusedAdamWEMA
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    torch.manual_seed(0)
+    gpu = torch.device("cuda:0")
+    unet = EDMPrecond(img_resolution=32, img_channels=3, model_channels=64, channel_mult=[1, 2, 2, 2], num_blocks=1,
+                      attn_resolutions=[16, 8], dropout=0.1, augment_dim=9)
+    dpm = DDPM(model=unet, image_size=[32, 32], perceptual_weight=0.0, cfg=dict(eps=1e-4, weighting_loss=False)).to(gpu).train()
+    flat = FlatParams(dpm)
+    opt = FusedAdamWEMA(flat, lr=2e-3, weight_decay=0.0, max_norm=1.0, ema=True)
+    g = torch.Generator(device=gpu).manual_seed(1)
+    batch = {"image": torch.rand(16, 3, 32, 32, device=gpu, generator=g) * 2 - 1}
+    t = torch.rand(16, device=gpu, generator=g) * 0.8 + 0.1
+    noise = torch.randn(16, 3, 32, 32, device=gpu, generator=g)
+    losses = []
+    for step in range(40):
+        flat.zero_grad()
+        loss, _ = dpm.training_step(batch, t=t, noise=noise)
+        loss.backward()
+        opt.step(ema_decay=0.9)
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses), "NaN in the loss"
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    # the EMA trails the weights but has moved away from the initial copy
+    assert float((opt.ema - flat.flat).abs().max()) > 0
