@@ -100,7 +100,51 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
   }
 }
 
+// One launch for ALL layers of a model: table[e] = {src, dst_fwd, dst_bwd, Co, Ci, taps, Co_pad, Ci_pad, qkv, total}
+// (int64 each); blockIdx.y = layer, blockIdx.x = 2048-element chunk (blocks past a layer's size exit at once).
+__global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict__ table) {
+  const long* t = table + (long)blockIdx.y * 10;
+  const long total = t[9];
+  const long base = (long)blockIdx.x * 2048;
+  if (base >= total) return;
+  const float* __restrict__ w = reinterpret_cast<const float*>(t[0]);
+  float* __restrict__ fwd = reinterpret_cast<float*>(t[1]);
+  float* __restrict__ bwd = reinterpret_cast<float*>(t[2]);
+  const int Co = (int)t[3], Ci = (int)t[4], taps = (int)t[5], Co_pad = (int)t[6], Ci_pad = (int)t[7], qkv = (int)t[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long idx = base + threadIdx.x + k * 256;
+    if (idx >= total) break;
+    {   // forward operand  [Co_pad][taps][Ci_pad]
+      int ci = idx % Ci_pad;
+      long r = idx / Ci_pad;
+      int tap = r % taps;
+      int cop = r / taps;
+      float v = 0.f;
+      if (cop < Co && ci < Ci) v = w[((long)(qkv ? qkv_to_ref(cop) : cop) * Ci + ci) * taps + tap];
+      fwd[idx] = v;
+    }
+    {   // data-gradient operand  [Ci_pad][taps flipped][Co_pad]
+      int cop = idx % Co_pad;
+      long r = idx / Co_pad;
+      int tapf = r % taps;
+      int ci = r / taps;
+      float v = 0.f;
+      if (cop < Co && ci < Ci) v = w[((long)(qkv ? qkv_to_ref(cop) : cop) * Ci + ci) * taps + (taps - 1 - tapf)];
+      bwd[idx] = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int adm_pack_weight_table(const long* table, int n_entries, long max_total, hipStream_t stream) {
+  if (!table || n_entries <= 0 || max_total <= 0) return ADM_EINVAL;
+  dim3 grid((unsigned)((max_total + 2047) / 2048), (unsigned)n_entries);
+  hipLaunchKernelGGL(pack_table_kernel, grid, dim3(256), 0, stream, table);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
 
 extern "C" int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci, int ks, int Co_pad,
                                int Ci_pad, int qkv, hipStream_t stream) {

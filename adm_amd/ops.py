@@ -10,6 +10,7 @@ Each Function's backward is hand-written HIP as well -- autograd is only the tap
 from __future__ import annotations
 
 import itertools
+import weakref
 from typing import Optional
 
 import torch
@@ -117,7 +118,10 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
         call("adm_permute_vec", ptr(b), ptr(ent.bias), co, cop, int(qkv), 0)
     try:
         weight._adm_packed = ent
-    except AttributeError:
+        _pack_registry[id(weight)] = (weakref.ref(weight), None if bias is None else weakref.ref(bias), ks, qkv)
+        global _pack_table
+        _pack_table = None
+    except (AttributeError, TypeError):
         pass
     return ent
 
@@ -125,6 +129,51 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
 def invalidate_packed():
     global _pack_epoch
     _pack_epoch += 1
+
+
+# Registry of live packed parameters, so that the optimiser can refresh ALL packed operands with one launch
+# (adm_pack_weight_table) instead of two small launches per layer on first use after every step.
+_pack_registry: dict = {}
+_pack_table = None          # (device int64 table, [entries], max_total)
+
+
+def repack_all():
+    """Called by the fused optimiser after it rewrote the flat parameter buffer: re-derives every registered packed
+    operand in place with one kernel launch and marks the entries current."""
+    global _pack_table, _pack_epoch
+    _pack_epoch += 1
+    if _pack_table is None:
+        rows, ents = [], []
+        for key, (wref, bref, ks, qkv) in list(_pack_registry.items()):
+            w = wref()
+            ent = getattr(w, "_adm_packed", None) if w is not None else None
+            if w is None or ent is None or not w.is_cuda:
+                _pack_registry.pop(key, None)
+                continue
+            co, ci = w.shape[0], w.shape[1]
+            cop, cip = ceil32(co), ceil32(ci)
+            rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv),
+                         cop * ks * ks * cip])
+            ents.append((wref, bref, ks, qkv, ent))
+        if not rows:
+            return
+        dev = ents[0][0]().device
+        _pack_table = (torch.tensor(rows, dtype=torch.int64, device=dev), ents, max(r[9] for r in rows), rows)
+    table, ents, max_total, rows = _pack_table
+    for (wref, bref, ks, qkv, ent), row in zip(ents, rows):      # storage moved or parameter died -> rebuild lazily
+        w = wref()
+        if w is None or w.data_ptr() != row[0] or getattr(w, "_adm_packed", None) is not ent:
+            _pack_table = None
+            return
+    call("adm_pack_weight_table", ptr(table), len(ents), max_total)
+    for wref, bref, ks, qkv, ent in ents:
+        w = wref()
+        b = bref() if bref is not None else None
+        co = w.shape[0]
+        if b is not None and (qkv or ceil32(co) != co):
+            call("adm_permute_vec", ptr(b.detach()), ptr(ent.bias), co, ceil32(co), int(qkv), 0)
+        ent.fwd16 = ent.bwd16 = None
+        ent.key = (w.data_ptr(), w._version, _pack_epoch, ks, qkv, None if b is None else (b.data_ptr(), b._version))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -161,7 +161,7 @@ class FusedAdamWEMA:
              float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
              float(self.wd), float(self.max_norm), self.step_count, float(ema_decay if ema_decay is not None else 0.0),
              float(grad_scale))
-        ops.invalidate_packed()      # parameters changed through raw pointers
+        ops.repack_all()             # parameters changed through raw pointers: refresh every packed operand (1 launch)
 
     def grad_norm(self, grad_scale: float = 1.0) -> float:
         return float(self.sumsq.sqrt()) * grad_scale

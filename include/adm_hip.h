@@ -73,6 +73,10 @@ int adm_f32_to_bf16(const float* src, unsigned short* dst, long n, hipStream_t s
  * Either output may be NULL. */
 int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci, int ks, int Co_pad, int Ci_pad,
                     int qkv, hipStream_t stream);
+/* adm_pack_weight for every layer of a model in ONE launch (used after each optimiser step).  table = device array of
+ * n_entries rows of 10 int64: {src, dst_fwd, dst_bwd, Co, Ci, ks*ks, Co_pad, Ci_pad, qkv, Co_pad*ks*ks*Ci_pad};
+ * max_total = the largest last column. */
+int adm_pack_weight_table(const long* table, int n_entries, long max_total, hipStream_t stream);
 /* inverse of the fwd packing for gradients: dw OIHW = (accumulate ? dw : 0) + dwp */
 int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
                      int accumulate, hipStream_t stream);
