@@ -52,21 +52,30 @@ def parse():
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="run warmup+steps only (for rocprofv3)")
     ap.add_argument("--small", action="store_true", help="reduced-width model (debug only; result marked invalid)")
+    ap.add_argument("--config", choices=["cifar", "latent"], default="cifar",
+                    help="cifar = BASELINE configs[1] (default, the headline metric); latent = the UNet of configs[3] "
+                         "(uncond_unet_sd_2 on 64x64x3 latents, model_channels 128; default --batch 32; no autoencoder)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="contraction precision of conv/Linear: f32 = BASELINE configs[1] (default, exact fp32 MFMA); "
                          "bf16 = configs[2] mode (bf16 MFMA operands, fp32 accumulate/storage)")
     return ap.parse_args()
 
 
-def build_model(dev, small=False):
+def build_model(dev, small=False, config="cifar"):
     from adm_amd.ddm.ddm_const import DDPM
     from adm_amd.unet.uncond_unet import EDMPrecond
     kw = dict(model_channels=192, channel_mult=[1, 2, 2, 2], channel_mult_emb=4, num_blocks=3, attn_resolutions=[16, 8],
               dropout=0.1, label_dropout=0, augment_dim=9)
+    res = 32
+    if config == "latent":      # celeb_uncond_ddm_const2_unet_ldm.yaml:42-55 (the reference's released-weights family)
+        from adm_amd.ddm.ddm_const_2 import DDPM
+        from adm_amd.unet.uncond_unet_sd_2 import EDMPrecond
+        kw.update(model_channels=128, augment_dim=0)
+        res = 64
     if small:
         kw.update(model_channels=64, num_blocks=1)
     torch.manual_seed(1234)
-    unet = EDMPrecond(img_resolution=32, img_channels=3, sigma_data=1.0, model_type="DhariwalUNet", **kw)
+    unet = EDMPrecond(img_resolution=res, img_channels=3, sigma_data=1.0, model_type="DhariwalUNet", **kw)
     # the reference zero-initialises conv1 / proj (dead branches at step 0); give them the Dhariwal init
     # so the benchmark exercises every kernel with non-trivial data, as a mid-training model would
     with torch.no_grad():
@@ -75,10 +84,12 @@ def build_model(dev, small=False):
                 fan_in = p[0].numel()
                 p.copy_((torch.rand_like(p) * 2 - 1) * (1.0 / fan_in) ** 0.5)
     mcfg = dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True, use_augment=False, ldm=False)
+    if config == "latent":
+        mcfg.update(eps=1e-3, sigma_min=0.001)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        dpm = DDPM(model=unet, image_size=[32, 32], sampling_timesteps=10, loss_type="l2", start_dist="normal",
+        dpm = DDPM(model=unet, image_size=[res, res], sampling_timesteps=10, loss_type="l2", start_dist="normal",
                    perceptual_weight=0.0, use_l1=False, cfg=mcfg)
     return dpm.to(dev)
 
@@ -142,7 +153,7 @@ def main():
     hip.lib()
     ops.set_compute_precision(args.dtype)
 
-    dpm = build_model(dev, args.small)
+    dpm = build_model(dev, args.small, args.config)
     dpm.train()
     flat = FlatParams(dpm)
     if use_dist:    # identical start on every rank
@@ -150,9 +161,10 @@ def main():
     reducer = BucketedGradReducer(flat, force=force_dist)
     log(f"world={world} rank={rank} buckets={len(reducer.buckets)} reducer_active={reducer.active}")
     opt = FusedAdamWEMA(flat, lr=1e-4, weight_decay=1e-4, max_norm=1.0, ema=(rank == 0))
-    B = args.batch
+    B = args.batch if (args.config == "cifar" or args.batch != 128) else 32
+    R = 32 if args.config == "cifar" else 64
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
-    batches = [{"image": torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1} for _ in range(2)]
+    batches = [{"image": torch.rand(B, 3, R, R, device=dev, generator=gen) * 2 - 1} for _ in range(2)]
 
     def train_step(it):
         flat.zero_grad()
@@ -255,24 +267,27 @@ def main():
             tmax = torch.tensor([st], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             st = float(tmax)
-        assert img.dtype == torch.float64 and img.shape == (B, 3, 32, 32)
+        assert img.dtype == torch.float64 and img.shape == (B, 3, R, R)
         sample_ips = world * B / st
         log(f"sample({B}) took {st:.3f}s")
 
     if rank == 0:
-        out = {"metric": "train images/sec (CIFAR-10 32x32 uncond DDM UNet, 1 optimizer step/iter) + 10-step sample images/sec",
+        what = "CIFAR-10 32x32 uncond DDM UNet" if args.config == "cifar" else "64x64x3-latent uncond DDM UNet (configs[3], UNet only)"
+        out = {"metric": f"train images/sec ({what}, 1 optimizer step/iter) + 10-step sample images/sec",
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
                "sample_images_per_sec": None if sample_ips is None else round(sample_ips, 2),
-               "config": {"workload": ("BASELINE configs[1]" if args.dtype == "f32" else "BASELINE configs[2] (per-GPU share)") +
-                                      ": CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), "
-                                      f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, ddm_const schedule, dropout 0.1, loss_simple (LPIPS term needs "
+               "config": {"workload": ("BASELINE configs[3] UNET ONLY (uncond_unet_sd_2, model_channels 128, 64x64x3 latents, "
+                                       "ddm_const_2; the frozen KL-f4 autoencoder is not part of this build): " if args.config == "latent"
+                                       else ("BASELINE configs[1]" if args.dtype == "f32" else "BASELINE configs[2] (per-GPU share)") +
+                                       ": CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), ") +
+                                      f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, {'ddm_const' if args.config == 'cifar' else 'ddm_const_2'} schedule, dropout 0.1, loss_simple (LPIPS term needs "
                                       "unfetchable VGG16 weights), clip 1.0 + AdamW + EMA(every 8)",
-                          "global_batch": world * B, "image": "3x32x32", "sampling_timesteps": 10,
+                          "global_batch": world * B, "image": f"3x{R}x{R}", "sampling_timesteps": 10,
                           "parallelism": f"dp{world}", "valid": not args.small},
                "final_loss": round(final_loss, 4), "roofline": roof}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "cifar":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -211,3 +211,36 @@ def test_ops_refuse_cpu_tensors():
     from adm_amd import ops
     with pytest.raises(RuntimeError):
         ops.silu(torch.zeros(4))
+
+
+def test_latent_unet_config3_vs_oracle(gpu):
+    """BASELINE configs[3]'s UNet (configs/celebahq/celeb_uncond_ddm_const2_unet_ldm.yaml:42-55 in the reference):
+    single-decoder uncond_unet_sd_2 on 64x64x3 latents, model_channels=128, attention at 16x16 / 8x8 -- forward and
+    gradients against the CPU oracle (the KL-f4 autoencoder around it is not part of this build)."""
+    import importlib
+    cfg = unet_ref.default_cfg(variant="uncond_unet_sd_2", img_resolution=64, model_channels=128, num_blocks=1,
+                               attn_resolutions=[16, 8], dropout=0.0, augment_dim=0)
+    mod = importlib.import_module("unet.uncond_unet_sd_2")
+    kw = {k: cfg[k] for k in ("model_channels", "channel_mult", "channel_mult_emb", "num_blocks", "attn_resolutions",
+                              "dropout", "augment_dim")}
+    m = mod.EDMPrecond(img_resolution=64, img_channels=3, model_type="DhariwalUNet", **kw)
+    sd = fill.filled_state_dict(unet_ref.param_shapes(cfg))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu).eval()
+    x = fill.hash_tensor((2, 3, 64, 64), "z", 1.0)
+    sigma = torch.tensor([0.3, 0.9])
+    dx, dy = m(x.to(gpu), sigma.to(gpu))
+    sdo = {k: v.clone().requires_grad_("resample" not in k) for k, v in sd.items()}
+    ox, oy = unet_ref.edm_precond(sdo, cfg, x, sigma)
+    close(dx, ox.detach()); close(dy, oy.detach())
+    gx = fill.hash_tensor(dx.shape, "gz", 1.0)
+    ((dx * gx.to(gpu)).sum() + (dy * gx.to(gpu)).sum()).backward()
+    ((ox * gx).sum() + (oy * gx).sum()).backward()
+    gmax = max(float(v.grad.double().norm()) for v in sdo.values() if v.grad is not None)
+    bad = []
+    for name, p in m.named_parameters():
+        want = sdo[name].grad
+        err = float((p.grad.cpu().double() - want.double()).norm() / (want.double().norm() + 1e-6 * gmax))
+        if err > 2e-3:
+            bad.append((name, err))
+    assert not bad, bad[:10]
