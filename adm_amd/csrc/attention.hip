@@ -1,5 +1,6 @@
 // Self-attention core of UNetBlock (/root/reference/unet/uncond_unet.py:205-208):
-//   w = softmax_k(q^T k / sqrt(64)),  a = w v          per (batch, head), head dim 64, L = H*W <= 256
+//   w = softmax_k(q^T k / sqrt(64)),  a = w v          per (batch, head), head dim 64, L = H*W (<= 256 in one
+//   chunk; longer sequences, e.g. L = 1024 of the 64x64-latent configs, in 256-row chunks with an online softmax)
 // on the fp32-input MFMA (exact fp32, so the rtol 1e-3 / atol 1e-4 parity bar holds without any
 // reduced-precision caveat).
 //
@@ -84,55 +85,74 @@ __device__ __forceinline__ void store_T(const f32x16 (&o)[2], float* rowptr, boo
     }
 }
 
-template <int NKT>
+// Sequences longer than one chunk (CH = NKT*32 keys, at most 256) are processed flash-style: gridDim.y = number of
+// 256-row chunks the workgroup OWNS one of (queries for fwd / dq, keys for dkv) and it loops over all chunks of the
+// other side, re-filling LDS each time; the forward keeps a running max / sum per query (online softmax).
+template <int NKT, bool MULTI>
 __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_fwd_kernel(const float* __restrict__ qkv,
                                                                            float* __restrict__ out,
                                                                            float* __restrict__ lse, int L, int heads) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CH = NKT * 32;
   float* Ks = smem;
-  float* Vs = smem + NKT * 32 * KS;
+  float* Vs = smem + CH * KS;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const long rs = (long)heads * 192;
   const float* base = qkv + (long)b * L * rs + h * 192;
-  // zero-fill rows >= L (only when L < 32) so masked keys read finite values
-  for (int i = tid; i < NKT * 32 * KS * 2; i += blockDim.x) smem[i] = 0.f;
-  __syncthreads();
-  load_rows_to_lds(Ks, base + 64, rs, L, tid, blockDim.x);
-  load_rows_to_lds(Vs, base + 128, rs, L, tid, blockDim.x);
-  const int q = wid * 32 + lr;
+  const int nchunks = MULTI ? (L + CH - 1) / CH : 1;     // single-chunk instantiation: no rescale code, no spills
+  const int q = blockIdx.y * CH + wid * 32 + lr;
   const bool qok = q < L;
   f32x4 qf[8];
   load_frag(qf, base + (long)q * rs, qok, lh, 0.125f);
-  __syncthreads();
 
-  f32x16 s[NKT];
-  float m = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    s[kt] = rows_times_frag(Ks + kt * 32 * KS, qf, lr, lh);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (kt * 32 + acc_row(r, lh) >= L) s[kt][r] = -INFINITY;
-      m = fmaxf(m, s[kt][r]);
-    }
-  }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float l = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float e = __expf(s[kt][r] - m);
-      s[kt][r] = e;
-      l += e;
-    }
-  l += __shfl_xor(l, 32, 64);
+  float m = -INFINITY, l = 0.f;
   f32x16 o[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+#pragma unroll 1
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int k0 = kc * CH, kn = min(CH, L - k0);
+    __syncthreads();                                   // previous chunk fully consumed
+    if (kn < CH) {                                     // zero-fill so masked keys read finite values
+      for (int i = tid; i < CH * KS * 2; i += blockDim.x) smem[i] = 0.f;
+      __syncthreads();
+    }
+    load_rows_to_lds(Ks, base + (long)k0 * rs + 64, rs, kn, tid, blockDim.x);
+    load_rows_to_lds(Vs, base + (long)k0 * rs + 128, rs, kn, tid, blockDim.x);
+    __syncthreads();
+    f32x16 s[NKT];
+    float mc = -INFINITY;
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) accum_T(o, Vs, kt * 32, s[kt], lr, lh);
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = rows_times_frag(Ks + kt * 32 * KS, qf, lr, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kt * 32 + acc_row(r, lh) >= kn) s[kt][r] = -INFINITY;
+        mc = fmaxf(mc, s[kt][r]);
+      }
+    }
+    mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+    const float mn = fmaxf(m, mc);
+    if constexpr (MULTI) {
+      const float sc = (m == -INFINITY) ? 0.f : __expf(m - mn);    // rescale of what has been accumulated so far
+      l *= sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= sc; o[1][r] *= sc; }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = __expf(s[kt][r] - mn);
+        s[kt][r] = e;
+        l += e;
+      }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) accum_T(o, Vs, kt * 32, s[kt], lr, lh);
+    m = mn;
+  }
+  l += __shfl_xor(l, 32, 64);                          // the two wave halves hold disjoint keys of the same query
   store_T(o, out + ((long)b * L + q) * heads * 64 + h * 64, qok, lh, 1.f / l);
   if (qok && lh == 0 && lse) lse[((long)b * heads + h) * L + q] = m + __logf(l);
 }
@@ -145,17 +165,15 @@ __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dq_kernel(
     const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ dqkv, float* __restrict__ delta, int L, int heads) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CH = NKT * 32;
   float* Ks = smem;
-  float* Vs = smem + NKT * 32 * KS;
+  float* Vs = smem + CH * KS;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const long rs = (long)heads * 192, ro = (long)heads * 64;
   const float* base = qkv + (long)b * L * rs + h * 192;
-  for (int i = tid; i < NKT * 32 * KS * 2; i += blockDim.x) smem[i] = 0.f;
-  __syncthreads();
-  load_rows_to_lds(Ks, base + 64, rs, L, tid, blockDim.x);
-  load_rows_to_lds(Vs, base + 128, rs, L, tid, blockDim.x);
-  const int q = wid * 32 + lr;
+  const int nchunks = (L + CH - 1) / CH;
+  const int q = blockIdx.y * CH + wid * 32 + lr;
   const bool qok = q < L;
   f32x4 qf[8], gf[8];
   load_frag(qf, base + (long)q * rs, qok, lh, 0.125f);
@@ -171,21 +189,32 @@ __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dq_kernel(
   dl += __shfl_xor(dl, 32, 64);
   const float ls = qok ? lse[((long)b * heads + h) * L + q] : 0.f;
   if (qok && lh == 0) delta[((long)b * heads + h) * L + q] = dl;
-  __syncthreads();
 
   f32x16 dq[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
 #pragma unroll 1
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x16 s = rows_times_frag(Ks + kt * 32 * KS, qf, lr, lh);
-    f32x16 dp = rows_times_frag(Vs + kt * 32 * KS, gf, lr, lh);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = (kt * 32 + acc_row(r, lh) < L) ? __expf(s[r] - ls) : 0.f;
-      s[r] = p * (dp[r] - dl);                    // dS^T[key][q]
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int k0 = kc * CH, kn = min(CH, L - k0);
+    __syncthreads();
+    if (kn < CH) {
+      for (int i = tid; i < CH * KS * 2; i += blockDim.x) smem[i] = 0.f;
+      __syncthreads();
     }
-    accum_T(dq, Ks, kt * 32, s, lr, lh);
+    load_rows_to_lds(Ks, base + (long)k0 * rs + 64, rs, kn, tid, blockDim.x);
+    load_rows_to_lds(Vs, base + (long)k0 * rs + 128, rs, kn, tid, blockDim.x);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 s = rows_times_frag(Ks + kt * 32 * KS, qf, lr, lh);
+      f32x16 dp = rows_times_frag(Vs + kt * 32 * KS, gf, lr, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = (kt * 32 + acc_row(r, lh) < kn) ? __expf(s[r] - ls) : 0.f;
+        s[r] = p * (dp[r] - dl);                    // dS^T[key][q]
+      }
+      accum_T(dq, Ks, kt * 32, s, lr, lh);
+    }
   }
   store_T(dq, dqkv + ((long)b * L + q) * rs + h * 192, qok, lh, 0.125f);
 }
@@ -198,45 +227,54 @@ __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dkv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, float* __restrict__ dqkv, int L, int heads) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                          // [NKT*32][KS]
-  float* Gs = smem + NKT * 32 * KS;          // dO rows
-  float* Ls = Gs + NKT * 32 * KS;            // lse[NKT*32] | delta[NKT*32]
+  constexpr int CH = NKT * 32;
+  float* Qs = smem;                          // [CH][KS]
+  float* Gs = smem + CH * KS;                // dO rows
+  float* Ls = Gs + CH * KS;                  // lse[CH] | delta[CH]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const long rs = (long)heads * 192, ro = (long)heads * 64;
   const float* base = qkv + (long)b * L * rs + h * 192;
-  for (int i = tid; i < NKT * 32 * KS * 2; i += blockDim.x) smem[i] = 0.f;
-  __syncthreads();
-  load_rows_to_lds(Qs, base, rs, L, tid, blockDim.x);
-  load_rows_to_lds(Gs, dout + (long)b * L * ro + h * 64, ro, L, tid, blockDim.x);
-  for (int i = tid; i < NKT * 32; i += blockDim.x) {
-    Ls[i] = i < L ? lse[((long)b * heads + h) * L + i] : 0.f;
-    Ls[NKT * 32 + i] = i < L ? delta[((long)b * heads + h) * L + i] : 0.f;
-  }
-  const int key = wid * 32 + lr;
+  const int nchunks = (L + CH - 1) / CH;
+  const int key = blockIdx.y * CH + wid * 32 + lr;
   const bool kok = key < L;
   f32x4 kf[8], vf[8];
   load_frag(kf, base + (long)key * rs + 64, kok, lh, 0.125f);
   load_frag(vf, base + (long)key * rs + 128, kok, lh, 1.f);
-  __syncthreads();
 
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 #pragma unroll 1
-  for (int qt = 0; qt < NKT; ++qt) {
-    f32x16 s = rows_times_frag(Qs + qt * 32 * KS, kf, lr, lh);      // S[q][key] (already / 8)
-    f32x16 dp = rows_times_frag(Gs + qt * 32 * KS, vf, lr, lh);     // dP[q][key]
-    f32x16 ds;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int qq = qt * 32 + acc_row(r, lh);
-      float p = (qq < L) ? __expf(s[r] - Ls[qq]) : 0.f;
-      s[r] = p;
-      ds[r] = p * (dp[r] - Ls[NKT * 32 + qq]);
+  for (int qc = 0; qc < nchunks; ++qc) {
+    const int q0 = qc * CH, qn = min(CH, L - q0);
+    __syncthreads();
+    if (qn < CH) {
+      for (int i = tid; i < CH * KS * 2; i += blockDim.x) smem[i] = 0.f;
+      __syncthreads();
     }
-    accum_T(dv, Gs, qt * 32, s, lr, lh);
-    accum_T(dk, Qs, qt * 32, ds, lr, lh);
+    load_rows_to_lds(Qs, base + (long)q0 * rs, rs, qn, tid, blockDim.x);
+    load_rows_to_lds(Gs, dout + ((long)b * L + q0) * ro + h * 64, ro, qn, tid, blockDim.x);
+    for (int i = tid; i < CH; i += blockDim.x) {
+      Ls[i] = i < qn ? lse[((long)b * heads + h) * L + q0 + i] : 0.f;
+      Ls[CH + i] = i < qn ? delta[((long)b * heads + h) * L + q0 + i] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int qt = 0; qt < NKT; ++qt) {
+      f32x16 s = rows_times_frag(Qs + qt * 32 * KS, kf, lr, lh);      // S[q][key] (already / 8)
+      f32x16 dp = rows_times_frag(Gs + qt * 32 * KS, vf, lr, lh);     // dP[q][key]
+      f32x16 ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int qq = qt * 32 + acc_row(r, lh);
+        float p = (qq < qn) ? __expf(s[r] - Ls[qq]) : 0.f;
+        s[r] = p;
+        ds[r] = p * (dp[r] - Ls[CH + qq]);
+      }
+      accum_T(dv, Gs, qt * 32, s, lr, lh);
+      accum_T(dk, Qs, qt * 32, ds, lr, lh);
+    }
   }
   float* orow = dqkv + ((long)b * L + key) * rs + h * 192;
   store_T(dk, orow + 64, kok, lh, 0.125f);
@@ -251,8 +289,10 @@ int launch_attn(int which, const float* qkv, const float* out, const float* dout
   const int smem_dkv = smem_kv + NKT * 32 * 2 * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<NKT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<NKT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_kv);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<NKT, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem_kv);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<NKT>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem_kv);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<NKT>),
@@ -260,9 +300,10 @@ int launch_attn(int which, const float* qkv, const float* out, const float* dout
     if (e != hipSuccess) return ADM_ELAUNCH;
     attr_set = true;
   }
-  dim3 grid(B * heads), block(64 * NW);
+  dim3 grid(B * heads, (L + NKT * 32 - 1) / (NKT * 32)), block(64 * NW);
   if (which == 0) {
-    hipLaunchKernelGGL((attn_fwd_kernel<NKT>), grid, block, smem_kv, st, qkv, o_out, lse, L, heads);
+    if (grid.y > 1) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true>), grid, block, smem_kv, st, qkv, o_out, lse, L, heads);
+    else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), grid, block, smem_kv, st, qkv, o_out, lse, L, heads);
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT>), grid, block, smem_kv, st, qkv, out, dout, lse, dqkv, delta, L, heads);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT>), grid, block, smem_dkv, st, qkv, dout, lse, delta, dqkv, L, heads);
@@ -273,10 +314,10 @@ int launch_attn(int which, const float* qkv, const float* out, const float* dout
 
 int dispatch_attn(int which, const float* qkv, const float* out, const float* dout, float* o_out, float* lse,
                   float* dqkv, float* delta, int B, int L, int heads, hipStream_t st) {
-  if (!qkv || B <= 0 || heads <= 0 || L <= 0 || L > 256) return ADM_EINVAL;
+  if (!qkv || B <= 0 || heads <= 0 || L <= 0 || L > 65536) return ADM_EINVAL;
   if (L > 32 && (L % 32) != 0) return ADM_EINVAL;
   if ((uintptr_t)qkv & 15) return ADM_EINVAL;
-  const int nkt = (L + 31) / 32;
+  const int nkt = L > 256 ? 8 : (L + 31) / 32;        // longer sequences: 256-row chunks, flash-style
   switch (nkt) {
     case 1: return launch_attn<1>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st);
     case 2: return launch_attn<2>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st);

@@ -110,7 +110,8 @@ int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float*
 /* ---------------- self-attention core -------------------------------------------------------- */
 
 /* qkv [B][L][heads*192] packed (head, {q,k,v}, 64); out [B][L][heads*64].
- * out = softmax_k(q.k / 8) v per (b, head): uncond_unet.py:205-208.  L <= 32 or a multiple of 32 up to 256. */
+ * out = softmax_k(q.k / 8) v per (b, head): uncond_unet.py:205-208.  L <= 32 or a multiple of 32; sequences beyond
+ * 256 (L = 1024 at the 32x32 level of the 64x64-latent configs) run in 256-row chunks with an online softmax. */
 int adm_attn_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, hipStream_t stream);
 /* lse [B*heads][L] = log-sum-exp per query saved by the forward (may be NULL there when no backward
  * follows); delta [B*heads][L] scratch.  dqkv has the qkv layout.  Autograd of :205-208. */

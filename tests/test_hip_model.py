@@ -244,3 +244,35 @@ def test_latent_unet_config3_vs_oracle(gpu):
         if err > 2e-3:
             bad.append((name, err))
     assert not bad, bad[:10]
+
+
+def test_latent_unet_with_32x32_attention_vs_oracle(gpu):
+    """celeb_uncond_ddm_const_uncond_unet_ldm.yaml:42-55: attn_resolutions [32, 16] on 64x64 latents -> L = 1024
+    attention through the chunked (online-softmax) kernels; two-decoder variant, reduced depth."""
+    import importlib
+    cfg = unet_ref.default_cfg(variant="uncond_unet", img_resolution=64, model_channels=64, num_blocks=1,
+                               attn_resolutions=[32, 16], dropout=0.0, augment_dim=0)
+    mod = importlib.import_module("unet.uncond_unet")
+    kw = {k: cfg[k] for k in ("model_channels", "channel_mult", "channel_mult_emb", "num_blocks", "attn_resolutions",
+                              "dropout", "augment_dim")}
+    m = mod.EDMPrecond(img_resolution=64, img_channels=3, model_type="DhariwalUNet", **kw)
+    sd = fill.filled_state_dict(unet_ref.param_shapes(cfg))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu).eval()
+    x = fill.hash_tensor((2, 3, 64, 64), "z", 1.0)
+    sigma = torch.tensor([0.3, 0.9])
+    dx, dy = m(x.to(gpu), sigma.to(gpu))
+    sdo = {k: v.clone().requires_grad_("resample" not in k) for k, v in sd.items()}
+    ox, oy = unet_ref.edm_precond(sdo, cfg, x, sigma)
+    close(dx, ox.detach()); close(dy, oy.detach())
+    gx = fill.hash_tensor(dx.shape, "gz", 1.0)
+    ((dx * gx.to(gpu)).sum() + (dy * gx.to(gpu)).sum()).backward()
+    ((ox * gx).sum() + (oy * gx).sum()).backward()
+    gmax = max(float(v.grad.double().norm()) for v in sdo.values() if v.grad is not None)
+    bad = []
+    for name, p in m.named_parameters():
+        want = sdo[name].grad
+        err = float((p.grad.cpu().double() - want.double()).norm() / (want.double().norm() + 1e-6 * gmax))
+        if err > 2e-3:
+            bad.append((name, err))
+    assert not bad, bad[:10]

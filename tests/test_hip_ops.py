@@ -171,7 +171,7 @@ def test_dropout_mask_is_consistent(ops):
     close(nchw(gx), xr.grad)
 
 
-@pytest.mark.parametrize("L,heads", [(16, 6), (64, 6), (256, 6), (64, 1), (256, 2)])
+@pytest.mark.parametrize("L,heads", [(16, 6), (64, 6), (256, 6), (64, 1), (256, 2), (1024, 2), (576, 1)])   # > 256: chunked, online softmax
 def test_attention(ops, L, heads):
     B, h, C = 2, int(math.isqrt(L)), 64 * heads
     qkv = fill.hash_tensor((B, 3 * C, h, h), f"attn{L}.{heads}", 1.5).requires_grad_(True)
