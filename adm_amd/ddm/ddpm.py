@@ -101,6 +101,26 @@ class DDPMBase(nn.Module):
         """x_t = x0 + C t + g(t) eps with C = -x0 (the only C the wrapper ever uses)."""
         return ops.q_sample(x_start, noise, t.to(torch.float32), self._sched)
 
+    def pred_x0_from_xt(self, xt, noise, C, t):
+        """x0 = x_t - C t - g(t) eps (ddm_const.py:290-293 / ddm_const_2.py:179-182).  API-parity helper: the samplers
+        do this inside their fused HIP step kernels; this standalone form is [B]-broadcast elementwise math."""
+        time = t.reshape(C.shape[0], *((1,) * (C.dim() - 1)))
+        return xt - C * time - self._g(time) * noise
+
+    def pred_xtms_from_xt(self, xt, noise, C, t, s, epsilon=None):
+        """One stochastic reverse step (ddm_const.py:296-303 / ddm_const_2.py:185-197); `epsilon` injectable."""
+        time = t.reshape(C.shape[0], *((1,) * (C.dim() - 1)))
+        s = s.reshape(C.shape[0], *((1,) * (C.dim() - 1)))
+        if self.SCHEDULE == "const":
+            mean = xt + C * (time - s) - C * time - s / torch.sqrt(time) * noise
+            sigma = torch.sqrt(s * (time - s) / time)
+        else:
+            mean = xt - C * s - (2 * s * time - s ** 2) / time * noise
+            sigma = torch.sqrt(2 * s * time - s ** 2) * (time - s) / time
+        if epsilon is None:
+            epsilon = torch.randn_like(mean)
+        return mean + sigma * epsilon
+
     def loss_weights(self, t):
         eps = self._eps_f
         if not self.weighting_loss:
