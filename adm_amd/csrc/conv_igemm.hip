@@ -12,12 +12,17 @@
 //   math       : v_mfma_f32_32x32x2_f32 -- exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD,
 //                which is the fp32 peak of the chip (157 TFLOP/s); no reduced precision anywhere.
 //
-// Tiling: 256 threads = 4 waves; workgroup tile BM x BN, K-step 32; A and B tiles staged through
-// LDS as [row][32+4] floats (the +4 pad makes the ds_read_b128 fragment reads conflict-free:
-// 16-lane groups hit 16 distinct 4-bank slots), register-staged double buffering with one barrier
-// per K-step.  Each lane reads float4 = 4 consecutive k of its row; lanes 0-31 take k 0-3 of an
-// 8-group and lanes 32-63 take k 4-7, so MFMA j of the group consumes k = j (low half) and
-// k = 4 + j (high half) -- a fixed permutation of the k order applied to A and B alike.
+// Tiling: 256 threads = 4 waves; workgroup tile BM x BN, K-step 32, double-buffered LDS, one barrier per K-step.
+// Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): the tiles go global -> LDS with no VGPR round trip, no
+// ds_write and no vector-ALU work (which matters doubly here: the fp32 MFMA shares the SIMD's fp32 lanes).  One
+// wave instruction writes 1 KiB = 8 rows x 32 floats LINEARLY, so rows cannot be padded; instead the 16-byte
+// slots of a row are XOR-swizzled with (row >> 1) & 7 -- applied to the per-lane SOURCE address on the way in and
+// to the ds_read_b128 address on the way out -- which spreads the 16 rows read by a lane group over the 16 slots
+// of a 256-byte bank-row pair (conflict-free).  The buffer descriptor's range check writes ZEROS for out-of-image
+// taps / edge rows (offset 0x80000000), which is the convolution's zero padding.
+// Each lane reads float4 = 4 consecutive k of its row; lanes 0-31 take k 0-3 of an 8-group and lanes 32-63 take
+// k 4-7, so MFMA j of the group consumes k = j (low half) and k = 4 + j (high half) -- a fixed permutation of the
+// k order applied to A and B alike.
 #include "common.h"
 #include "../../include/adm_hip.h"
 
@@ -27,14 +32,16 @@ struct IgemmP {
   const float* x; const float* w; const float* bias; const float* res; float* y;
   int M, N, H, W, Hin, Win, Cin, ldx, K, ldy, ldr, ks, up, wrows, tilesN, xbytes, wbytes;
   int splitk, kt_per_split; float* ws;     // split-K: partial tiles go to ws[z][M][N], summed by splitk_reduce_kernel
+  int stride, cshift;                      // input centre of output (oy, ox) = (oy*stride + cshift, ox*stride + cshift)
 };
 
-constexpr int LDSS = 36;   // floats per LDS row (32 + 4 pad)
+constexpr int LDSS = 32;   // floats per LDS row (unpadded: LDS-DMA writes linearly; slots are XOR-swizzled)
+typedef __attribute__((address_space(3))) void lds_void;
 
 template <int BM, int BN, int WM, int WN, bool UP>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32);
-  constexpr int AI = BM / 32, BI = BN / 32;
+  constexpr int AI = BM / 32, BI = BN / 32;         // LDS-DMA instructions per wave per stage (8 rows each)
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][BM][LDSS]
@@ -56,16 +63,11 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   const int tm = bid % tilesM, tn = bid / tilesM;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- loader state: each thread owns float4 column c4 of rows r0 + 32 i ----
-  // Addressing is done with raw BUFFER loads so that almost no vector ALU work is left in the K loop
-  // (on gfx950 the fp32 MFMA shares the SIMD's fp32 lanes: every VALU instruction in the loop is MFMA time
-  // lost -- measured: the staging code cost 17 % before this):
-  //   * per row a 32-bit byte offset `voff` that already includes the current tap; it is recomputed only when
-  //     the tap changes (every Cin/32 K-steps), and set to 0x80000000 for rows / taps outside the image;
-  //   * the channel-chunk offset rides in the instruction's scalar offset;
-  //   * the buffer descriptor's range check returns ZERO for the 0x80000000 rows, which implements the zero
-  //     padding (and the M / N edge masking) with no select instructions at all.
-  const int c4 = tid & 7, r0 = tid >> 3;
+  // ---- loader state.  DMA instruction i of wave w fills rows (w*I + i)*8 .. +7 of the tile: lane -> row +(lane>>3),
+  // physical 16-byte slot lane&7, and it must FETCH logical slot (lane&7) ^ ((row>>1)&7) of that row.
+  // Per row a 32-bit byte offset that already includes the current tap; recomputed only when the tap changes (every
+  // Cin/32 K-steps) and set to 0x80000000 (-> zeros from the range check) for rows / taps outside the image; the
+  // channel-chunk offset rides in the instruction's scalar offset: no vector ALU work per K-step at all.
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.wbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
@@ -73,7 +75,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   const int pad = p.ks >> 1;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    int m = m0 + r0 + 32 * i;
+    const int row = (wid * AI + i) * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
     bool ok = m < p.M;
     int mm = ok ? m : 0;
     int ox = mm % p.W;
@@ -81,12 +85,16 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
     int oy = t % p.H;
     int b = t / p.H;
     unsigned mask = 0;
+    // centre (tap (1,1) of a 3x3) in the coordinates the bounds are tested in: the up-sampled grid for UP, else the
+    // input image; a strided conv (the KL autoencoder's Downsample) moves it to oy*stride + (1 - pad_lo)
+    const int cy = UP ? oy : oy * p.stride + p.cshift, cx = UP ? ox : ox * p.stride + p.cshift;
+    const int HB = UP ? p.H : p.Hin, WB = UP ? p.W : p.Win;
     if (ok) {
       if (p.ks == 3) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
-          int iy = oy + tp / 3 - 1, ix = ox + tp % 3 - 1;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << tp;
+          int iy = cy + tp / 3 - 1, ix = cx + tp % 3 - 1;
+          if ((unsigned)iy < (unsigned)HB && (unsigned)ix < (unsigned)WB) mask |= 1u << tp;
         }
       } else {
         mask = 1u;
@@ -95,8 +103,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
     // for the fused nearest-x2 the tap offset depends on the parity of (oy, ox): keep it in the high bits
     if (UP) mask |= ((unsigned)(oy & 1) << 16) | ((unsigned)(ox & 1) << 17);
     a_mask[i] = mask;
-    int py = UP ? (oy >> 1) : oy, px = UP ? (ox >> 1) : ox;
-    a_pix[i] = (unsigned)(((b * p.Hin + py) * p.Win + px) * p.ldx + c4 * 4) * 4u;     // byte offset of the centre pixel
+    int py = UP ? (oy >> 1) : cy, px = UP ? (ox >> 1) : cx;
+    a_pix[i] = (unsigned)(((b * p.Hin + py) * p.Win + px) * p.ldx + ls * 4) * 4u;     // byte offset of the centre pixel
     a_voff[i] = OOB;
   }
   const int cchunks = p.Cin >> 5;
@@ -110,14 +118,15 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
   unsigned b_voff[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    int n = n0 + r0 + 32 * i;
-    b_voff[i] = (n < p.wrows) ? (unsigned)(n * p.K + c4 * 4) * 4u : OOB;
+    const int row = (wid * BI + i) * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    b_voff[i] = (n < p.wrows) ? (unsigned)(n * p.K + ls * 4) * 4u : OOB;
   }
 
-  f32x4 ra[AI], rb[BI];
   int ld_tap = s_begin / cchunks, ld_cc = s_begin - ld_tap * cchunks;   // (tap, channel chunk) of the NEXT stage to load
   bool a_fresh = true;             // a split-K range may start in the middle of a tap
-  auto load_stage = [&]() {
+  auto issue_stage = [&](int buf) {
     const int tap = ld_tap;
     if (ld_cc == 0 || a_fresh) {   // new tap: rebuild the per-row offsets (wave-uniform branch, every Cin/32 steps)
       a_fresh = false;
@@ -137,22 +146,20 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
     }
     const int c0b = ld_cc << 7;                                  // 32 floats = 128 bytes per chunk
     const int kb = (tap * p.Cin) * 4 + c0b;
+    float* la = As + buf * BM * LDSS + wid * AI * 8 * LDSS;
+    float* lb = Bs + buf * BN * LDSS + wid * BI * 8 * LDSS;
 #pragma unroll
     for (int i = 0; i < AI; ++i)
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[i], c0b, 0));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(la + i * 8 * LDSS), 16, (int)a_voff[i], c0b, 0, 0);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
-      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)b_voff[i], kb, 0));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(lb + i * 8 * LDSS), 16, (int)b_voff[i], kb, 0, 0);
     if (++ld_cc == cchunks) { ld_cc = 0; ++ld_tap; }
   };
-  auto store_stage = [&](int buf) {
-    float* Ab = As + buf * BM * LDSS;
-    float* Bb = Bs + buf * BN * LDSS;
+  // fragment offsets (floats) inside a 32-row block for g = 0..3: row lr, physical slot (2g + lh) ^ ((lr >> 1) & 7)
+  int foff[4];
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&Ab[(r0 + 32 * i) * LDSS + c4 * 4]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bb[(r0 + 32 * i) * LDSS + c4 * 4]) = rb[i];
-  };
+  for (int g = 0; g < 4; ++g) foff[g] = lr * LDSS + (((2 * g + lh) ^ ((lr >> 1) & 7)) << 2);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -162,22 +169,21 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_stage();
-  store_stage(0);
-  __syncthreads();
+  issue_stage(0);
+  __syncthreads();                 // (the compiler drains the DMA with s_waitcnt vmcnt(0) ahead of the barrier)
 
   for (int s = 0; s < KT; ++s) {
     const int buf = s & 1;
-    if (s + 1 < KT) load_stage();
-    const float* Ab = As + buf * BM * LDSS + (wm * MT * 32 + lr) * LDSS + lh * 4;
-    const float* Bb = Bs + buf * BN * LDSS + (wn * NT * 32 + lr) * LDSS + lh * 4;
+    if (s + 1 < KT) issue_stage(buf ^ 1);        // buffer buf^1 was last read in step s-1; every wave passed its barrier
+    const float* Ab = As + buf * BM * LDSS + wm * MT * 32 * LDSS;
+    const float* Bb = Bs + buf * BN * LDSS + wn * NT * 32 * LDSS;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 a[MT], b[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS + g * 8);
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDSS + foff[g]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS + g * 8);
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDSS + foff[g]);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -186,7 +192,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < KT) store_stage(buf ^ 1);
     __syncthreads();
   }
 
@@ -295,19 +300,22 @@ extern "C" int adm_conv_fwd_ws(const float* x, const float* wp, const float* bia
                                float* ws, long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows,
                                int ldy, int ldr, int ks, int up, hipStream_t stream);
 
-extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float* res, float* y,
-                            int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
-                            int ks, int up, int tile, hipStream_t stream) {
-  if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
+namespace {
+int conv_fwd_impl(const float* x, const float* wp, const float* bias, const float* res, float* y, int B, int H, int W,
+                  int Hin, int Win, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks, int up, int stride,
+                  int pad_lo, int tile, hipStream_t stream) {
+  if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || Hin <= 0 || Win <= 0) return ADM_EINVAL;
   if ((Cin & 31) || (ldx & 3) || (ks != 1 && ks != 3) || N <= 0 || wrows < N) return ADM_EINVAL;
   if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
   if (((uintptr_t)x | (uintptr_t)wp) & 15) return ADM_EINVAL;
+  if ((long)B * H * W >= (1L << 31)) return ADM_EINVAL;
   IgemmP p;
   p.x = x; p.w = wp; p.bias = bias; p.res = res; p.y = y;
   p.M = B * H * W; p.N = N; p.H = H; p.W = W;
-  p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
+  p.Hin = Hin; p.Win = Win;
   p.Cin = Cin; p.ldx = ldx; p.K = ks * ks * Cin; p.ldy = ldy; p.ldr = ldr; p.ks = ks; p.up = up; p.wrows = wrows;
   p.tilesN = 0; p.splitk = 1; p.kt_per_split = 0; p.ws = nullptr;
+  p.stride = stride; p.cshift = (ks >> 1) - pad_lo;
   const long xb = (long)B * p.Hin * p.Win * ldx * 4, wb = (long)wrows * p.K * 4;
   if (xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;     // 32-bit buffer offsets; 0x80000000 must stay out of range
   p.xbytes = (int)xb; p.wbytes = (int)wb;
@@ -336,6 +344,27 @@ extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, 
     default: return ADM_EINVAL;
   }
 }
+}  // namespace
+
+extern "C" int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float* res, float* y,
+                            int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                            int ks, int up, int tile, hipStream_t stream) {
+  return conv_fwd_impl(x, wp, bias, res, y, B, H, W, up ? H / 2 : H, up ? W / 2 : W, Cin, ldx, N, wrows, ldy, ldr, ks,
+                       up, 1, ks >> 1, tile, stream);
+}
+
+// Strided conv with explicit (possibly asymmetric) zero padding: tap (ky, kx) of output (oy, ox) reads input
+// (oy*stride + ky - pad_lo, ox*stride + kx - pad_lo); whatever falls outside [0, Hin) x [0, Win) is zero, which covers
+// any bottom/right padding.  The KL autoencoder's Downsample (pad (0,1,0,1) + 3x3 stride 2:
+// /root/reference/ddm/encoder_decoder.py:78-96) is stride = 2, pad_lo = 0, Hout = Hin / 2.
+extern "C" int adm_conv_fwd_strided(const float* x, const float* wp, const float* bias, const float* res, float* y,
+                                    int B, int Hin, int Win, int Hout, int Wout, int Cin, int ldx, int N, int wrows,
+                                    int ldy, int ldr, int ks, int stride, int pad_lo, hipStream_t stream) {
+  if (stride < 1 || stride > 4 || pad_lo < 0 || pad_lo > (ks >> 1) || Hout <= 0 || Wout <= 0) return ADM_EINVAL;
+  if ((long)(Hout - 1) * stride - pad_lo >= Hin || (long)(Wout - 1) * stride - pad_lo >= Win) return ADM_EINVAL;
+  return conv_fwd_impl(x, wp, bias, res, y, B, Hout, Wout, Hin, Win, Cin, ldx, N, wrows, ldy, ldr, ks, 0, stride,
+                       pad_lo, -1, stream);
+}
 
 // Same as adm_conv_fwd with a caller-provided workspace: when adm_conv_splitk(M, N, K) > 1 the K range is split
 // over gridDim.y, partial tiles go to ws[splitk][M][N] and a second launch sums them (+ bias, + residual) in a
@@ -357,7 +386,7 @@ extern "C" int adm_conv_fwd_ws(const float* x, const float* wp, const float* bia
   p.M = (int)M; p.N = N; p.H = H; p.W = W;
   p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.K = K; p.ldy = ldy; p.ldr = ldr; p.ks = ks; p.up = up; p.wrows = wrows;
-  p.tilesN = 0;
+  p.tilesN = 0; p.stride = 1; p.cshift = 0;
   const long xb = (long)B * p.Hin * p.Win * ldx * 4, wb = (long)wrows * p.K * 4;
   if (xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;
   p.xbytes = (int)xb; p.wbytes = (int)wb;

@@ -375,6 +375,85 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 }  // namespace
 
+namespace {
+// In-place row softmax of scale * s: one workgroup per row, the row cached in registers (cols <= 256 * 4 * 8).
+// Used by the KL autoencoder's single-head mid-block attention (/root/reference/ddm/encoder_decoder.py:196-204),
+// whose 4096 x 4096 score matrix per image is produced / consumed by the implicit-GEMM kernel.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int cols, long ld, float scale) {
+  __shared__ float red[4];
+  float* row = s + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x, nv = cols >> 2;
+  f32x4 v[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = tid + i * 256;
+    if (q < nv) {
+      v[i] = *reinterpret_cast<const f32x4*>(row + 4 * q) * scale;
+      mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = tid + i * 256;
+    if (q < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][j] = __expf(v[i][j] - mx); sum += v[i][j]; }
+    }
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = tid + i * 256;
+    if (q < nv) *reinterpret_cast<f32x4*>(row + 4 * q) = v[i] * inv;
+  }
+}
+
+// z = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps  over NHWC moments [M][ldm] = (mean[0:C] | logvar[C:2C])
+// (DiagonalGaussianDistribution.sample, /root/reference/ddm/encoder_decoder.py:855-867); eps NULL -> the mode.
+__global__ void posterior_sample_kernel(const float* __restrict__ mom, int ldm, const float* __restrict__ eps,
+                                        float* __restrict__ z, int ldz, long M, int C, float zscale) {
+  const long total = M * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C;
+    const int c = (int)(i - m * C);
+    const float mean = mom[m * ldm + c];
+    float r = mean;
+    if (eps) {
+      const float lv = fminf(fmaxf(mom[m * ldm + C + c], -30.0f), 20.0f);
+      r = mean + expf(0.5f * lv) * eps[i];
+    }
+    z[m * ldz + c] = r * zscale;
+  }
+}
+}  // namespace
+
+extern "C" int adm_softmax_rows(float* s, long rows, int cols, long ld, float scale, hipStream_t stream) {
+  if (!s || rows <= 0 || rows >= (1L << 31) || cols <= 0 || (cols & 3) || cols > 8192 || ld < cols || (ld & 3)) return ADM_EINVAL;
+  if ((uintptr_t)s & 15) return ADM_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, s, cols, ld, scale);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_posterior_sample(const float* moments, int ldm, const float* eps, float* z, int ldz, long M, int C,
+                                    float zscale, hipStream_t stream) {
+  if (!moments || !z || M <= 0 || C <= 0 || ldm < 2 * C || ldz < C) return ADM_EINVAL;
+  hipLaunchKernelGGL(posterior_sample_kernel, dim3(ew_grid(M * C)), dim3(256), 0, stream, moments, ldm, eps, z, ldz, M, C, zscale);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
 extern "C" int adm_version(void) { return 1; }
 
 extern "C" int adm_resample2x(const float* x, float* y, int B, int H, int W, int C, int mode, float scale, int acc,

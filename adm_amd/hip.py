@@ -22,6 +22,7 @@ _SIGS = {
     "adm_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_splitk": [I, I, I],
     "adm_conv_fwd_ws": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_fwd_strided": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
@@ -35,6 +36,8 @@ _SIGS = {
     "adm_gn_stats": [P, P, P, I, I, I, I, F, P],
     "adm_gn_apply": [P, P, P, P, P, L, P, I, I, I, I, I, F, U, P],
     "adm_gn_bwd": [P, P, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, F, U, P],
+    "adm_softmax_rows": [P, L, I, L, F, P],
+    "adm_posterior_sample": [P, I, P, P, I, L, I, F, P],
     "adm_attn_fwd": [P, P, P, I, I, I, P],
     "adm_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "adm_resample2x": [P, P, I, I, I, I, I, F, I, P],

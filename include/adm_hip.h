@@ -40,6 +40,15 @@ int adm_conv_fwd(const float* x, const float* wp, const float* bias, const float
                  int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                  int ks, int up, int tile, hipStream_t stream);
 
+/* adm_conv_fwd with a stride and explicit top/left zero padding: tap (ky, kx) of output (oy, ox) reads input
+ * (oy*stride + ky - pad_lo, ox*stride + kx - pad_lo); anything outside the Hin x Win image is zero (this is the
+ * bottom/right padding).  The KL-f4 autoencoder's Downsample -- F.pad(x, (0,1,0,1)) + Conv2d(3x3, stride 2, padding 0),
+ * /root/reference/ddm/encoder_decoder.py:78-96 -- is stride 2, pad_lo 0, Hout = Hin/2.  Forward only (the first stage is
+ * frozen: /root/reference/ddm/ddm_const_2.py:436-440). */
+int adm_conv_fwd_strided(const float* x, const float* wp, const float* bias, const float* res, float* y,
+                         int B, int Hin, int Win, int Hout, int Wout, int Cin, int ldx, int N, int wrows,
+                         int ldy, int ldr, int ks, int stride, int pad_lo, hipStream_t stream);
+
 /* Deterministic split-K for the small-M layers (4x4 resolution, embedding Linears): adm_conv_splitk(M, N, K) is the
  * number of K slices the library would use (1 = none); adm_conv_fwd_ws is adm_conv_fwd with a workspace of at least
  * splitk*M*N floats: partial tiles are written there and summed (+ bias, + res) in a fixed order by a second launch. */
@@ -106,6 +115,17 @@ int adm_gn_apply(const float* x, const float* stats, const float* gamma, const f
 int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta, float* red,
                int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);
+
+/* ---------------- KL autoencoder (first stage) helpers ---------------------------------------- */
+
+/* In-place s[r][0:cols] = softmax(scale * s[r][0:cols]) for `rows` rows of stride ld: the single-head
+ * (d = C = 512) attention of the autoencoder's mid block, whose QK^T and PV products run on adm_conv_fwd
+ * (/root/reference/ddm/encoder_decoder.py:190-213).  cols % 4 == 0, cols <= 8192. */
+int adm_softmax_rows(float* s, long rows, int cols, long ld, float scale, hipStream_t stream);
+/* z[m][c] = zscale * (mean + exp(0.5*clamp(logvar,-30,20)) * eps[m*C+c]); moments rows = (mean[0:C] | logvar[C:2C]);
+ * eps == NULL gives the mode.  DiagonalGaussianDistribution.sample (/root/reference/ddm/encoder_decoder.py:855-867). */
+int adm_posterior_sample(const float* moments, int ldm, const float* eps, float* z, int ldz, long M, int C,
+                         float zscale, hipStream_t stream);
 
 /* ---------------- self-attention core -------------------------------------------------------- */
 
