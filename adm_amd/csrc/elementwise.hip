@@ -280,6 +280,43 @@ __global__ __launch_bounds__(256) void ddm_loss_kernel(const float* __restrict__
   if (threadIdx.x == 0) atomicAdd(&per_sample[b], red[0] + red[1] + red[2] + red[3]);
 }
 
+// Latent variant (ddm_const_2.py:527-596): the weighted SSE above plus  w3 * sum |x_rec - x0|,
+// x_rec = x_t - C_pred t - t noise_pred  (const_2: g(t) = t), evaluated in the reference's operation order.
+// w = [B][3] = (w1, w2, w3);  per_sample[b] gets the SSE part, per_l1[b] the UN-weighted L1 sum.
+__global__ __launch_bounds__(256) void ddm_loss_latent_kernel(const float* __restrict__ cp, const float* __restrict__ np_,
+                                                              const float* __restrict__ x0, const float* __restrict__ noise,
+                                                              const float* __restrict__ xt, const float* __restrict__ t,
+                                                              const float* __restrict__ w, float* __restrict__ per_sample,
+                                                              float* __restrict__ per_l1, float* __restrict__ dc,
+                                                              float* __restrict__ dn, float gscale, long n) {
+  __shared__ float red[8];
+  const int b = blockIdx.x;
+  const float w1 = w[3 * b], w2 = w[3 * b + 1], w3 = w[3 * b + 2], tb = t[b];
+  float acc = 0.f, l1 = 0.f;
+  for (long i = blockIdx.y * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.y * blockDim.x) {
+    long k = (long)b * n + i;
+    float c = cp[k], e = np_[k];
+    float e1 = c + x0[k];
+    float e2 = e - noise[k];
+    float d = ((xt[k] - c * tb) - tb * e) - x0[k];
+    acc += w1 * e1 * e1 + w2 * e2 * e2;
+    l1 += fabsf(d);
+    if (dc) {
+      float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      float g3 = -w3 * tb * sg;
+      dc[k] = gscale * (2.f * w1 * e1 + g3);
+      dn[k] = gscale * (2.f * w2 * e2 + g3);
+    }
+  }
+  acc = wave_sum(acc); l1 = wave_sum(l1);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = acc; red[4 + (threadIdx.x >> 6)] = l1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&per_sample[b], red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(&per_l1[b], red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
 __global__ void sampler_step_kernel(double* __restrict__ x, const float* __restrict__ cp, const float* __restrict__ np_,
                                     double t_cur, double t_next, double g_cur, double g_next, int clip_x0,
                                     double scale_input, int last, long n) {
@@ -585,6 +622,21 @@ extern "C" int adm_ddm_loss(const float* c_pred, const float* n_pred, const floa
   if (chunks > 64) chunks = 64;
   hipLaunchKernelGGL(ddm_loss_kernel, dim3(B, chunks), dim3(256), 0, stream, c_pred, n_pred, x0, noise, w, per_sample,
                      d_c, d_n, gscale, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+extern "C" int adm_ddm_loss_latent(const float* c_pred, const float* n_pred, const float* x0, const float* noise,
+                                   const float* xt, const float* t, const float* w, float* per_sample, float* per_l1,
+                                   float* d_c, float* d_n, float gscale, int B, long n, hipStream_t stream) {
+  if (!c_pred || !n_pred || !x0 || !noise || !xt || !t || !w || !per_sample || !per_l1 || B <= 0 || n <= 0) return ADM_EINVAL;
+  if ((d_c == nullptr) != (d_n == nullptr)) return ADM_EINVAL;
+  if (hipMemsetAsync(per_sample, 0, sizeof(float) * B, stream) != hipSuccess) return ADM_ELAUNCH;
+  if (hipMemsetAsync(per_l1, 0, sizeof(float) * B, stream) != hipSuccess) return ADM_ELAUNCH;
+  int chunks = (int)((n + 1023) / 1024);
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(ddm_loss_latent_kernel, dim3(B, chunks), dim3(256), 0, stream, c_pred, n_pred, x0, noise, xt, t, w,
+                     per_sample, per_l1, d_c, d_n, gscale, n);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -54,6 +54,7 @@ _SIGS = {
     "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, I, I, I, P],
     "adm_q_sample": [P, P, P, P, I, L, I, P],
     "adm_ddm_loss": [P, P, P, P, P, P, P, P, F, I, L, P],
+    "adm_ddm_loss_latent": [P, P, P, P, P, P, P, P, P, P, P, F, I, L, P],
     "adm_sampler_step": [P, P, P, D, D, I, I, D, I, L, P],
     "adm_sampler_step_stochastic": [P, P, P, P, P, P, I, I, D, I, I, L, P],
     "adm_sumsq": [P, P, L, P],

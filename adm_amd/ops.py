@@ -371,16 +371,16 @@ def next_dropout_seed() -> int:
 
 class _GroupNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed):
+    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed, groups=0, eps=1e-5):
         x = _chk(x, "x")
         B, H, W, C = x.shape
-        G = min(32, C // 4)
+        G = groups if groups else min(32, C // 4)
         HW = H * W
         g, b = _chk(gamma.detach(), "gamma"), _chk(beta.detach(), "beta")
         S = hip.lib().adm_gn_splits(HW, C)
         stats = _new((B, G, 2), x)
         ws = _new((B * S * G * 2,), x, torch.float64)
-        call("adm_gn_stats", ptr(x), ptr(stats), ptr(ws), B, HW, C, G, 1e-5)
+        call("adm_gn_stats", ptr(x), ptr(stats), ptr(ws), B, HW, C, G, float(eps))
         ssc, bstride = None, 0
         if ss is not None:
             ssc = _chk(ss, "scale_shift")
@@ -416,12 +416,14 @@ class _GroupNormAct(torch.autograd.Function):
              ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
         if direct:
             _notify(gamma); _notify(beta)
-            return dx, None, None, dss, None, None, None
-        return dx, dgamma, dbeta, dss, None, None, None
+            return dx, None, None, dss, None, None, None, None, None
+        return dx, dgamma, dbeta, dss, None, None, None, None, None
 
 
-def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0):
-    return _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed))
+def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5):
+    """groups = 0: the UNet's min(32, C // 4) (uncond_unet.py:119-129); the KL autoencoder passes 32 / 1e-6
+    (ddm/encoder_decoder.py:56-57)."""
+    return _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -656,6 +658,69 @@ def axpby_batch(y, x, a, s):
 
 
 # ------------------------------------------------------------------------------------------------
+# KL autoencoder (frozen first stage): forward-only helpers
+# ------------------------------------------------------------------------------------------------
+def _no_grad_only(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError("adm_amd: this op is forward-only (the first stage is frozen: ddm_const_2.py:436-440); "
+                           "call it under torch.no_grad() with parameters that do not require grad")
+
+
+def conv2d_strided(x, weight, bias=None, *, stride=2, pad_lo=0, pad_hi=1):
+    """NHWC conv with a stride and explicit zero padding (pad_lo rows/cols on the top/left, pad_hi on the bottom/right).
+    F.pad(x, (0,1,0,1)) + Conv2d(3x3, stride 2, padding 0) of the autoencoder's Downsample (encoder_decoder.py:78-96)
+    is stride=2, pad_lo=0, pad_hi=1.  Forward-only."""
+    _no_grad_only(x, weight, bias)
+    x = _chk(x, "x")
+    B, H, W, cx = x.shape
+    co, ci, ks = weight.shape[0], weight.shape[1], weight.shape[-1]
+    cop, cip = ceil32(co), ceil32(ci)
+    if cx != cip:
+        raise RuntimeError(f"conv input has {cx} channels, expected {cip}")
+    Ho, Wo = (H + pad_lo + pad_hi - ks) // stride + 1, (W + pad_lo + pad_hi - ks) // stride + 1
+    pk = packed(weight, bias, ks, False)
+    y = _new((B, Ho, Wo, cop), x)
+    with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"fwd-s{stride} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
+        call("adm_conv_fwd_strided", ptr(x), ptr(pk.fwd), ptr(pk.bias), None, ptr(y), B, H, W, Ho, Wo, cip, cip, cop, cop,
+             cop, cop, ks, stride, pad_lo)
+    return y
+
+
+def matmul_nt(a, b, bias=None, out=None):
+    """out[M][N] = sum_k a[m][k] * b[n][k] (+ bias[n]) on the implicit-GEMM kernel (a 1x1 'conv' over M pixels whose
+    weight matrix is b).  K % 32 == 0; rows 16-byte aligned.  Forward-only."""
+    _no_grad_only(a, b, bias)
+    a, b = _chk(a, "a"), _chk(b, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    if b.shape[1] != K or K % 32:
+        raise RuntimeError(f"matmul_nt: inner sizes {K} / {b.shape[1]} must match and be a multiple of 32")
+    y = out if out is not None else _new((M, N), a)
+    with _Prof("igemm", 2.0 * M * N * K, f"mm M={M} N={N} K={K}"):
+        call("adm_conv_fwd", ptr(a), ptr(b), ptr(bias), None, ptr(y), 1, M, 1, K, K, N, N, N, N, 1, 0, -1)
+    return y
+
+
+def softmax_rows_(s, scale: float):
+    """In place: s[r] = softmax(scale * s[r]) over the last dim of a contiguous 2-D fp32 tensor."""
+    hip.require_cuda(s, "s")
+    rows, cols = s.shape
+    call("adm_softmax_rows", ptr(s), rows, cols, cols, float(scale))
+    return s
+
+
+def posterior_sample(moments, C: int, eps=None, zscale: float = 1.0):
+    """moments NHWC [B,H,W,>=2C] (mean | logvar) -> z NHWC [B,H,W,C] = zscale * (mean + std * eps); eps NHWC [B,H,W,C]
+    or None for the mode (DiagonalGaussianDistribution, ddm/encoder_decoder.py:854-892)."""
+    moments = _chk(moments, "moments")
+    B, H, W, ld = moments.shape
+    z = _new((B, H, W, C), moments)
+    e = None if eps is None else _chk(eps, "eps")
+    call("adm_posterior_sample", ptr(moments), ld, ptr(e), ptr(z), C, B * H * W, C, float(zscale))
+    return z
+
+
+# ------------------------------------------------------------------------------------------------
 # analytic schedule
 # ------------------------------------------------------------------------------------------------
 def q_sample(x0, noise, t, schedule: int):
@@ -690,6 +755,34 @@ class _DdmLoss(torch.autograd.Function):
 
 def ddm_loss(c_pred, n_pred, x0, noise, w):
     return _DdmLoss.apply(c_pred, n_pred, _chk(x0, "x0"), _chk(noise, "noise"), _chk(w, "weights"))
+
+
+class _DdmLossLatent(torch.autograd.Function):
+    """LatentDiffusion.p_losses (ddm_const_2.py:527-596): weighted SSE + w3 * sum|x_rec - x0|.  Returns
+    (sum_b simple_b / B, per-sample simple, per-sample un-weighted L1)."""
+
+    @staticmethod
+    def forward(ctx, c_pred, n_pred, x0, noise, xt, t, w):
+        c_pred, n_pred = _chk(c_pred, "C_pred"), _chk(n_pred, "noise_pred")
+        B = c_pred.shape[0]
+        n = c_pred.numel() // B
+        per, l1 = _new((B,), c_pred), _new((B,), c_pred)
+        dc, dn = torch.empty_like(c_pred), torch.empty_like(n_pred)
+        call("adm_ddm_loss_latent", ptr(c_pred), ptr(n_pred), ptr(x0), ptr(noise), ptr(xt), ptr(t), ptr(w), ptr(per),
+             ptr(l1), ptr(dc), ptr(dn), 1.0 / B, B, n)
+        ctx.save_for_backward(dc, dn)
+        ctx.mark_non_differentiable(per, l1)
+        return (per.sum() + (l1 * w[:, 2]).sum()) / B, per, l1
+
+    @staticmethod
+    def backward(ctx, gloss, _gper, _gl1):
+        dc, dn = ctx.saved_tensors
+        return dc * gloss, dn * gloss, None, None, None, None, None
+
+
+def ddm_loss_latent(c_pred, n_pred, x0, noise, xt, t, w):
+    return _DdmLossLatent.apply(c_pred, n_pred, _chk(x0, "x0"), _chk(noise, "noise"), _chk(xt, "x_t"), _chk(t, "t"),
+                                _chk(w, "weights"))
 
 
 def sampler_step(x64, c_pred, n_pred, t_cur: float, t_next: float, schedule: int, clip_x0: bool, scale_input: float,

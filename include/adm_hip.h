@@ -193,6 +193,13 @@ int adm_q_sample(const float* x0, const float* noise, const float* t, float* xt,
  * w = [B][2] weights precomputed on device. */
 int adm_ddm_loss(const float* c_pred, const float* n_pred, const float* x0, const float* noise, const float* w,
                  float* per_sample, float* d_c, float* d_n, float gscale, int B, long n, hipStream_t stream);
+/* Latent-space loss (LatentDiffusion.p_losses, ddm_const_2.py:527-596, schedule const_2): the two weighted SSE terms
+ * of adm_ddm_loss plus w3[b] * sum |x_rec - x0| with x_rec = xt - Cp t - t Np.  w = [B][3] = (w1, w2, w3).
+ * per_sample[b] = SSE part, per_l1[b] = un-weighted L1 sum; dCp = gscale (2 w1 (Cp + x0) - w3 t sign(x_rec - x0)),
+ * dNp = gscale (2 w2 (Np - noise) - w3 t sign(x_rec - x0)).  Both outputs are zero-filled by the call. */
+int adm_ddm_loss_latent(const float* c_pred, const float* n_pred, const float* x0, const float* noise, const float* xt,
+                        const float* t, const float* w, float* per_sample, float* per_l1, float* d_c, float* d_n,
+                        float gscale, int B, long n, hipStream_t stream);
 /* One deterministic sampler update in fp64 (ddm_const.py:450-455 / ddm_const_2.py:363-368):
  * x0 = x - C t - eps g(t); [clamp]; x_next = x0 + C t' + eps g(t');  if last: clamp, /scale, (x+1)/2 */
 int adm_sampler_step(double* x, const float* c_pred, const float* n_pred, double t_cur, double t_next, int schedule,

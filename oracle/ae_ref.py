@@ -222,7 +222,7 @@ def std_scale_factor(z: Tensor) -> Tensor:
 
 def latent_p_losses(model_fn: Callable, z0: Tensor, t: Tensor, noise: Tensor, eps: float, weighting_loss: bool = True):
     """ddm_const_2.py:527-596 with use_l1 = False, use_disloss = False: the weighted SSE of the pixel-space wrapper
-    plus an L1 reconstruction term  loss_vlb = sum|x_rec - z0| * (-log t / 2)  (no LPIPS in latent space)."""
+    plus an L1 reconstruction term  loss_vlb = sum|x_rec - z0| * rec_weight  (no LPIPS in latent space)."""
     C = -1 * z0
     time = _bc(t, C)
     x_noisy = z0 + C * time + time * noise
@@ -235,7 +235,11 @@ def latent_p_losses(model_fn: Callable, z0: Tensor, t: Tensor, noise: Tensor, ep
     sse = lambda a, b: ((a - b) ** 2).sum(dim=[1, 2, 3])
     loss_simple = w1 * sse(C_pred, C) + w2 * sse(noise_pred, noise)
     B, n = C.shape[0], C[0].numel()
-    loss_vlb = (x_rec - z0).abs().sum([1, 2, 3]) * (-torch.log(t) / 2)
+    # NB reference quirk kept on purpose: rec_weight is reshaped to [B, 1] (ddm_const_2.py:566) and multiplied with the
+    # [B] vector of per-sample L1 sums (:568), which BROADCASTS to a [B, B] outer product; its .sum() is therefore
+    # (sum_b L1_b) * (sum_b' -log t_b' / 2): every sample's L1 term is weighted by the batch-sum of the rec weights.
+    rec_weight = -torch.log(t.reshape(B, 1)) / 2
+    loss_vlb = (x_rec - z0).abs().sum([1, 2, 3]) * rec_weight
     loss = loss_simple.sum() / B + loss_vlb.sum() / B
     log = {"train/loss_simple": loss_simple.detach().sum() / B / n,
            "train/loss_vlb": loss_vlb.detach().sum() / B / n,

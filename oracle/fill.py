@@ -47,6 +47,8 @@ def fill_value(name: str, shape: Tuple[int, ...]) -> torch.Tensor:
         s = (1.0 / fan_in) ** 0.5          # var = 1/(3 fan_in): the reference's Dhariwal init scale
         if ".q_conv" in name or ".k_conv" in name:
             s = 0.7
+        if ".q.weight" in name or ".k.weight" in name:     # autoencoder AttnBlock: make the softmax non-uniform
+            s = 3.0 * s
         return hash_tensor(shape, name, s)
     raise KeyError(name)
 
