@@ -22,6 +22,8 @@ class DDPM(DDPMBase):
 
 
 class LatentDiffusion(DDPM):
+    USES_LPIPS = False
+
     def __init__(self, auto_encoder, scale_factor=1.0, scale_by_std=True, scale_by_softsign=False, input_keys=("image",),
                  sample_type="naive", default_scale=False, *args, **kwargs):
         self.scale_by_std = scale_by_std

@@ -36,6 +36,7 @@ def _cfg_get(cfg, key, default):
 class DDPMBase(nn.Module):
     SCHEDULE = "const"          # 'const' -> g(t) = sqrt(t) ; 'const_2' -> g(t) = t
     DEFAULT_EPS = 1e-4
+    USES_LPIPS = True           # the pixel-space p_losses has the LPIPS term; LatentDiffusion's does not
 
     def __init__(self, model, *, image_size, sampling_timesteps=None, loss_type="l2", objective="pred_noise",
                  beta_schedule="cosine", clip_x_start=True, input_keys=("image",), start_dist="normal",
@@ -67,7 +68,7 @@ class DDPMBase(nn.Module):
             raise NotImplementedError("use_l1 is False in every DDM config; not implemented")
         self.use_l1 = use_l1
         self.perceptual_weight = perceptual_weight
-        if perceptual_weight > 0:
+        if perceptual_weight > 0 and self.USES_LPIPS:
             warnings.warn("adm_amd: the LPIPS term (perceptual_weight > 0) needs VGG16 weights that cannot be fetched "
                           "offline; loss_vlb is 0 (see DESIGN.md)", stacklevel=2)
         self.use_augment = bool(_cfg_get(cfg, "use_augment", False))

@@ -52,9 +52,11 @@ def parse():
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="run warmup+steps only (for rocprofv3)")
     ap.add_argument("--small", action="store_true", help="reduced-width model (debug only; result marked invalid)")
-    ap.add_argument("--config", choices=["cifar", "latent"], default="cifar",
-                    help="cifar = BASELINE configs[1] (default, the headline metric); latent = the UNet of configs[3] "
-                         "(uncond_unet_sd_2 on 64x64x3 latents, model_channels 128; default --batch 32; no autoencoder)")
+    ap.add_argument("--config", choices=["cifar", "latent", "latent-ae"], default="cifar",
+                    help="cifar = BASELINE configs[1] (default, the headline metric); latent = the UNet of configs[3] alone "
+                         "(uncond_unet_sd_2 on 64x64x3 latents, model_channels 128; default --batch 32); latent-ae = all of "
+                         "configs[3]: 256x256 images -> frozen KL-f4 autoencoder encode -> LatentDiffusion step; sampling "
+                         "ends with the decode to 256x256")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="contraction precision of conv/Linear: f32 = BASELINE configs[1] (default, exact fp32 MFMA); "
                          "bf16 = configs[2] mode (bf16 MFMA operands, fp32 accumulate/storage)")
@@ -67,7 +69,7 @@ def build_model(dev, small=False, config="cifar"):
     kw = dict(model_channels=192, channel_mult=[1, 2, 2, 2], channel_mult_emb=4, num_blocks=3, attn_resolutions=[16, 8],
               dropout=0.1, label_dropout=0, augment_dim=9)
     res = 32
-    if config == "latent":      # celeb_uncond_ddm_const2_unet_ldm.yaml:42-55 (the reference's released-weights family)
+    if config in ("latent", "latent-ae"):      # celeb_uncond_ddm_const2_unet_ldm.yaml:42-55 (the reference's released-weights family)
         from adm_amd.ddm.ddm_const_2 import DDPM
         from adm_amd.unet.uncond_unet_sd_2 import EDMPrecond
         kw.update(model_channels=128, augment_dim=0)
@@ -84,13 +86,24 @@ def build_model(dev, small=False, config="cifar"):
                 fan_in = p[0].numel()
                 p.copy_((torch.rand_like(p) * 2 - 1) * (1.0 / fan_in) ** 0.5)
     mcfg = dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True, use_augment=False, ldm=False)
-    if config == "latent":
+    if config in ("latent", "latent-ae"):
         mcfg.update(eps=1e-3, sigma_min=0.001)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        dpm = DDPM(model=unet, image_size=[res, res], sampling_timesteps=10, loss_type="l2", start_dist="normal",
-                   perceptual_weight=0.0, use_l1=False, cfg=mcfg)
+        if config == "latent-ae":     # celeb_uncond_ddm_const2_unet_ldm.yaml:1-40: KL-f4 first stage, default scale 0.165
+            from adm_amd.ddm.ddm_const_2 import LatentDiffusion
+            from adm_amd.ddm.encoder_decoder import AutoencoderKL
+            dd = dict(double_z=True, z_channels=3, resolution=[256, 256], in_channels=3, out_ch=3, ch=32 if small else 128,
+                      ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+            ae = AutoencoderKL(dd, dict(disc_start=20001, kl_weight=1e-6, disc_weight=0.5), 3)
+            mcfg.update(ldm=True, use_disloss=False)
+            dpm = LatentDiffusion(auto_encoder=ae, scale_factor=0.165, scale_by_std=True, default_scale=True, model=unet,
+                                  image_size=[256, 256], sampling_timesteps=10, loss_type="l2", start_dist="normal",
+                                  perceptual_weight=0.0, use_l1=False, cfg=mcfg)
+        else:
+            dpm = DDPM(model=unet, image_size=[res, res], sampling_timesteps=10, loss_type="l2", start_dist="normal",
+                       perceptual_weight=0.0, use_l1=False, cfg=mcfg)
     return dpm.to(dev)
 
 
@@ -162,7 +175,7 @@ def main():
     log(f"world={world} rank={rank} buckets={len(reducer.buckets)} reducer_active={reducer.active}")
     opt = FusedAdamWEMA(flat, lr=1e-4, weight_decay=1e-4, max_norm=1.0, ema=(rank == 0))
     B = args.batch if (args.config == "cifar" or args.batch != 128) else 32
-    R = 32 if args.config == "cifar" else 64
+    R = {"cifar": 32, "latent": 64, "latent-ae": 256}[args.config]
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
     batches = [{"image": torch.rand(B, 3, R, R, device=dev, generator=gen) * 2 - 1} for _ in range(2)]
 
@@ -267,23 +280,28 @@ def main():
             tmax = torch.tensor([st], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             st = float(tmax)
-        assert img.dtype == torch.float64 and img.shape == (B, 3, R, R)
+        assert img.shape == (B, 3, R, R) and img.dtype == (torch.float32 if args.config == "latent-ae" else torch.float64)
         sample_ips = world * B / st
         log(f"sample({B}) took {st:.3f}s")
 
     if rank == 0:
-        what = "CIFAR-10 32x32 uncond DDM UNet" if args.config == "cifar" else "64x64x3-latent uncond DDM UNet (configs[3], UNet only)"
+        what = {"cifar": "CIFAR-10 32x32 uncond DDM UNet", "latent": "64x64x3-latent uncond DDM UNet (configs[3], UNet only)",
+                "latent-ae": "CelebA-HQ-256-shaped latent DDM: frozen KL-f4 AE + 64x64x3-latent UNet (configs[3])"}[args.config]
         out = {"metric": f"train images/sec ({what}, 1 optimizer step/iter) + 10-step sample images/sec",
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
                "sample_images_per_sec": None if sample_ips is None else round(sample_ips, 2),
                "config": {"workload": ("BASELINE configs[3] UNET ONLY (uncond_unet_sd_2, model_channels 128, 64x64x3 latents, "
-                                       "ddm_const_2; the frozen KL-f4 autoencoder is not part of this build): " if args.config == "latent"
+                                       "ddm_const_2; no autoencoder in this line): " if args.config == "latent"
+                                       else "BASELINE configs[3]: 256x256 images -> frozen KL-f4 AutoencoderKL.encode (55M params, no "
+                                       "grad) -> LatentDiffusion (ddm_const_2, uncond_unet_sd_2 model_channels 128) training step; "
+                                       "sample = 10-step latent sampler + AutoencoderKL.decode to 256x256: " if args.config == "latent-ae"
                                        else ("BASELINE configs[1]" if args.dtype == "f32" else "BASELINE configs[2] (per-GPU share)") +
                                        ": CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), ") +
-                                      f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, {'ddm_const' if args.config == 'cifar' else 'ddm_const_2'} schedule, dropout 0.1, loss_simple (LPIPS term needs "
-                                      "unfetchable VGG16 weights), clip 1.0 + AdamW + EMA(every 8)",
+                                      f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, {'ddm_const' if args.config == 'cifar' else 'ddm_const_2'} schedule, dropout 0.1, " +
+                                      ("loss_simple + latent L1 term" if args.config == "latent-ae" else "loss_simple (LPIPS term needs unfetchable VGG16 weights)") +
+                                      ", clip 1.0 + AdamW + EMA(every 8)",
                           "global_batch": world * B, "image": f"3x{R}x{R}", "sampling_timesteps": 10,
                           "parallelism": f"dp{world}", "valid": not args.small},
                "final_loss": round(final_loss, 4), "roofline": roof}

@@ -20,8 +20,7 @@ import yaml
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from adm_amd.ddm.utils import construct_class_by_name  # noqa: E402
-from train_uncond_dpm import Cfg  # noqa: E402
+from train_uncond_dpm import Cfg, build_model  # noqa: E402
 
 
 def load_weights(model, path, use_ema, device):
@@ -30,6 +29,8 @@ def load_weights(model, path, use_ema, device):
         sd = {k[len("ema_model."):]: v for k, v in data["ema"].items() if k.startswith("ema_model.")}
     else:
         sd = data["model"] if "model" in data else data
+    if "model" in data and "scale_factor" in data["model"] and hasattr(model, "scale_factor"):     # reference :146-147
+        model.scale_factor = data["model"]["scale_factor"].to(device)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     print(f"loaded {path}: {len(missing)} missing, {len(unexpected)} unexpected keys")
 
@@ -47,9 +48,7 @@ def main():
     device = torch.device("cuda", local)
     torch.manual_seed(42 + rank)
     mc = cfg.model
-    unet = construct_class_by_name(**{k: v for k, v in mc.unet.items()})
-    dpm = construct_class_by_name(model=unet, cfg=mc, class_name=mc.class_name,
-                                  **{k: v for k, v in mc.items() if k not in ("class_name", "unet")}).to(device).eval()
+    dpm = build_model(mc).to(device).eval()          # pixel-space DDPM or LatentDiffusion (+ first stage), reference :50-64
     s = cfg.sampler
     if s.get("ckpt_path") and os.path.exists(s.ckpt_path):
         load_weights(dpm, s.ckpt_path, s.get("use_ema", True), device)

@@ -136,6 +136,8 @@ class Trainer:
 
     def load(self, milestone):
         data = torch.load(os.path.join(self.results, f"model-{milestone}.pt"), map_location=self.device, weights_only=True)
+        if "scale_factor" in data["model"] and hasattr(self.model, "scale_factor"):     # train_uncond_ldm.py:206-207
+            self.model.scale_factor = data["model"]["scale_factor"].to(self.device)
         self.model.load_state_dict(data["model"])
         self.step = data["step"]
         if isinstance(data.get("opt"), dict) and "exp_avg" in data["opt"]:
@@ -159,6 +161,10 @@ class Trainer:
             for ga in range(self.accum):
                 self.reducer.enabled = ga == self.accum - 1          # communicate on the last micro-step only
                 batch = next(self.stream)
+                if self.step == 0 and ga == 0 and hasattr(self.model, "on_train_batch_start"):
+                    self.model.on_train_batch_start(batch)       # latent models: std-rescaling from the first batch
+                    if self.world > 1 and isinstance(getattr(self.model, "scale_factor", None), torch.Tensor):
+                        dist.broadcast(self.model.scale_factor, src=0)      # one factor for all ranks
                 loss, log = self.model.training_step(batch)
                 (loss / self.accum).backward()
                 loss_acc += float(loss.detach()) / self.accum
@@ -192,6 +198,16 @@ class Trainer:
             print("training complete")
 
 
+def build_model(model_cfg):
+    """unet (+ frozen first stage when the YAML has model.first_stage) + diffusion wrapper, by dotted class name, as
+    /root/reference/train_uncond_dpm.py:40-46 and train_uncond_ldm.py:42-59 do."""
+    unet = construct_class_by_name(**{k: v for k, v in model_cfg.unet.items()})
+    kw = {k: v for k, v in model_cfg.items() if k not in ("class_name", "unet", "first_stage")}
+    if model_cfg.get("first_stage"):
+        kw["auto_encoder"] = construct_class_by_name(**{k: v for k, v in model_cfg.first_stage.items()})
+    return construct_class_by_name(model=unet, cfg=model_cfg, class_name=model_cfg.class_name, **kw)
+
+
 def main(args):
     cfg = Cfg(args.cfg)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -202,12 +218,11 @@ def main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     model_cfg = cfg.model
-    unet = construct_class_by_name(**{k: v for k, v in model_cfg.unet.items()})
-    kw = {k: v for k, v in model_cfg.items() if k not in ("class_name", "unet")}
-    dpm = construct_class_by_name(model=unet, cfg=model_cfg, class_name=model_cfg.class_name, **kw).to(device).train()
+    dpm = build_model(model_cfg).to(device).train()
     global_batch = int(cfg.data.batch_size)
     assert global_batch % world == 0, "split_batches: the YAML batch_size is the global batch"
-    stream = ImageStream(cfg.data, global_batch // world, tuple(model_cfg.image_size), device, seed=1000 + rank)
+    stream = ImageStream(cfg.data, global_batch // world, tuple(cfg.data.get("image_size") or model_cfg.image_size), device,
+                         seed=1000 + rank)
     trainer = Trainer(dpm, stream, cfg, device, rank, world)
     if cfg.trainer.get("test_before", False) and rank == 0:
         dpm.eval()
