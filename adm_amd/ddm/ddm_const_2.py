@@ -19,6 +19,7 @@ from .ddpm import DDPMBase, _cfg_get
 class DDPM(DDPMBase):
     SCHEDULE = "const_2"
     DEFAULT_EPS = 1e-4
+    AUGMENT_P = 0.12
 
 
 class LatentDiffusion(DDPM):

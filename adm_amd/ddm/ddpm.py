@@ -11,8 +11,8 @@ Differences, all documented in DESIGN.md:
   * every RNG draw (t, noise, x_T, sampler epsilons) can be injected for parity tests;
   * the LPIPS/VGG16 term needs fetched weights and cannot run offline: ``loss_vlb`` is 0 (the
     reference itself crashes in that configuration, ddm_const_2.py:251);
-  * ``use_augment`` feeds zero augment labels (the AugmentPipe geometry is data preparation, out of
-    the HIP scope this round) so the ``map_augment`` input is still honoured.
+  * ``use_augment`` runs the AugmentPipe on the GPU (adm_amd/ddm/augment.py) without the reference's per-step host
+    read-back of the padding margin; its draws are injectable (``augment_draws=``).
 """
 from __future__ import annotations
 
@@ -37,6 +37,7 @@ class DDPMBase(nn.Module):
     SCHEDULE = "const"          # 'const' -> g(t) = sqrt(t) ; 'const_2' -> g(t) = t
     DEFAULT_EPS = 1e-4
     USES_LPIPS = True           # the pixel-space p_losses has the LPIPS term; LatentDiffusion's does not
+    AUGMENT_P = 0.15            # AugmentPipe probability multiplier: 0.15 in ddm_const.py:179, 0.12 in ddm_const_2.py:112
 
     def __init__(self, model, *, image_size, sampling_timesteps=None, loss_type="l2", objective="pred_noise",
                  beta_schedule="cosine", clip_x_start=True, input_keys=("image",), start_dist="normal",
@@ -72,6 +73,9 @@ class DDPMBase(nn.Module):
             warnings.warn("adm_amd: the LPIPS term (perceptual_weight > 0) needs VGG16 weights that cannot be fetched "
                           "offline; loss_vlb is 0 (see DESIGN.md)", stacklevel=2)
         self.use_augment = bool(_cfg_get(cfg, "use_augment", False))
+        if self.use_augment:      # ddm_const.py:179-180 (p = 0.15) / ddm_const_2.py:112-113 (p = 0.12)
+            from .augment import AugmentPipe
+            self.augment = AugmentPipe(p=self.AUGMENT_P, xflip=1e8, yflip=1, scale=1, rotate_frac=1, aniso=1, translate_frac=1)
         self._eps_f = float(self.eps)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys, only_model)
@@ -154,10 +158,9 @@ class DDPMBase(nn.Module):
                 noise = torch.randn_like(x_start)
             else:
                 noise = 2 * torch.rand_like(x_start) - 1.0
-        if self.use_augment and "augment_labels" not in kwargs:
-            aug_dim = getattr(self.model.model.map_augment, "in_features", 0) if hasattr(self.model, "model") else 0
-            if aug_dim:
-                kwargs["augment_labels"] = torch.zeros(x_start.shape[0], aug_dim, device=x_start.device)
+        if self.use_augment and "augment_labels" not in kwargs:      # ddm_const.py:314-316 / ddm_const_2.py:206-208
+            x_start, kwargs["augment_labels"] = self.augment(x_start, draws=kwargs.pop("augment_draws", None))
+        kwargs.pop("augment_draws", None)
         x_start = x_start.to(torch.float32).contiguous()
         t = t.to(torch.float32).contiguous()
         x_noisy = self.q_sample(x_start, noise, t)

@@ -57,6 +57,8 @@ _SIGS = {
     "adm_ddm_loss_latent": [P, P, P, P, P, P, P, P, P, P, P, F, I, L, P],
     "adm_sampler_step": [P, P, P, D, D, I, I, D, I, L, P],
     "adm_sampler_step_stochastic": [P, P, P, P, P, P, I, I, D, I, I, L, P],
+    "adm_aug_workspace_floats": [I, I, I, I],
+    "adm_augment_geometric": [P, P, P, P, P, P, I, I, I, I, P],
     "adm_sumsq": [P, P, L, P],
     "adm_adamw_step": [P, P, P, P, P, P, L, F, F, F, F, F, F, I, F, F, P],
 }
@@ -83,7 +85,7 @@ def lib() -> ctypes.CDLL:
         for name, args in _SIGS.items():
             fn = getattr(_lib, name)      # AttributeError if the .so lacks a declared symbol
             fn.argtypes = args
-            fn.restype = c_int
+            fn.restype = c_long if name == "adm_aug_workspace_floats" else c_int
     return _lib
 
 

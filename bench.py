@@ -57,13 +57,16 @@ def parse():
                          "(uncond_unet_sd_2 on 64x64x3 latents, model_channels 128; default --batch 32); latent-ae = all of "
                          "configs[3]: 256x256 images -> frozen KL-f4 autoencoder encode -> LatentDiffusion step; sampling "
                          "ends with the decode to 256x256")
+    ap.add_argument("--augment", action="store_true",
+                    help="use_augment: True as in the reference's CIFAR YAML: AugmentPipe on x_start + 9 augment labels "
+                         "(SURVEY 8d asks for this as a second number; the headline line keeps it off)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="contraction precision of conv/Linear: f32 = BASELINE configs[1] (default, exact fp32 MFMA); "
                          "bf16 = configs[2] mode (bf16 MFMA operands, fp32 accumulate/storage)")
     return ap.parse_args()
 
 
-def build_model(dev, small=False, config="cifar"):
+def build_model(dev, small=False, config="cifar", augment=False):
     from adm_amd.ddm.ddm_const import DDPM
     from adm_amd.unet.uncond_unet import EDMPrecond
     kw = dict(model_channels=192, channel_mult=[1, 2, 2, 2], channel_mult_emb=4, num_blocks=3, attn_resolutions=[16, 8],
@@ -85,7 +88,7 @@ def build_model(dev, small=False, config="cifar"):
             if (name.endswith("conv1.weight") or name.endswith("proj.weight")) and float(p.abs().max()) == 0:
                 fan_in = p[0].numel()
                 p.copy_((torch.rand_like(p) * 2 - 1) * (1.0 / fan_in) ** 0.5)
-    mcfg = dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True, use_augment=False, ldm=False)
+    mcfg = dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True, use_augment=bool(augment), ldm=False)
     if config in ("latent", "latent-ae"):
         mcfg.update(eps=1e-3, sigma_min=0.001)
     import warnings
@@ -166,7 +169,7 @@ def main():
     hip.lib()
     ops.set_compute_precision(args.dtype)
 
-    dpm = build_model(dev, args.small, args.config)
+    dpm = build_model(dev, args.small, args.config, args.augment)
     dpm.train()
     flat = FlatParams(dpm)
     if use_dist:    # identical start on every rank
@@ -301,7 +304,7 @@ def main():
                                        ": CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), ") +
                                       f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, {'ddm_const' if args.config == 'cifar' else 'ddm_const_2'} schedule, dropout 0.1, " +
                                       ("loss_simple + latent L1 term" if args.config == "latent-ae" else "loss_simple (LPIPS term needs unfetchable VGG16 weights)") +
-                                      ", clip 1.0 + AdamW + EMA(every 8)",
+                                      ", clip 1.0 + AdamW + EMA(every 8)" + (", use_augment (AugmentPipe p=0.15 + labels)" if args.augment else ""),
                           "global_batch": world * B, "image": f"3x{R}x{R}", "sampling_timesteps": 10,
                           "parallelism": f"dp{world}", "valid": not args.small},
                "final_loss": round(final_loss, 4), "roofline": roof}

@@ -212,6 +212,17 @@ int adm_sampler_step_stochastic(double* x, const float* c_pred, const float* n_p
                                 const double* s, int schedule, int clip_x0, double scale_input, int last, int B, long n,
                                 hipStream_t stream);
 
+/* ---------------- augmentation of x_start (use_augment: True) ------------------------------- */
+
+/* Execution half of AugmentPipe for the transforms DDM enables (/root/reference/ddm/augment.py:161-172, 236-276;
+ * instantiated at ddm_const.py:179-180 / ddm_const_2.py:112-113): per-image x/y flips, reflect padding by the batch-wide
+ * `margin` = {mx0, my0, mx1, my1} (DEVICE ints: no host read-back), sym6 x2 up-sampling, bilinear affine resampling with
+ * theta[N][2][3] (normalised coordinates, align_corners = False, zeros outside), sym6 x2 down-sampling and crop.
+ * images / out: NCHW fp32 [N][C][H][W]; flips: int32 [N][2]; ws: adm_aug_workspace_floats(N, C, H, W) floats. */
+long adm_aug_workspace_floats(int N, int C, int H, int W);
+int adm_augment_geometric(const float* images, const int* flips, const int* margin, const float* theta, float* ws,
+                          float* out, int N, int C, int H, int W, hipStream_t stream);
+
 /* ---------------- optimiser (train_uncond_dpm.py:292-310, ddm/ema.py:158-188) ---------------- */
 
 /* sumsq[0] += sum g^2 */

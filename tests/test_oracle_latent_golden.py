@@ -99,3 +99,21 @@ def test_hip_autoencoder_refuses_cpu_tensors():
     ae = ED.AutoencoderKL(dd, {}, 3)
     with pytest.raises(RuntimeError):
         ae.encode(torch.zeros(1, 3, 32, 32))
+
+
+def test_augment_oracle_vs_golden(golden_dir):
+    """oracle/augment_ref.py against the reference AugmentPipe's outputs on recorded draws (g12)."""
+    from oracle import augment_ref as A
+    g = np.load(os.path.join(golden_dir, "g12_augment.npz"))
+    for tag, p, N, H, W, seed, force in (("p012", 0.12, 16, 32, 32, 11, 0.0), ("forced", 0.12, 8, 32, 32, 13, 0.9),
+                                          ("forced64", 0.15, 4, 64, 64, 14, 0.9), ("identity", 0.12, 4, 32, 32, 15, -2.0)):
+        x = fill.hash_tensor((N, 3, H, W), f"aug.{tag}.x", 1.0)
+        y, lab = A.augment(x, A.make_draws(N, seed, force), p)
+        close(lab, g[f"{tag}.labels"], 1e-6)
+        close(y, g[f"{tag}.images"])
+    # with no transform firing the pipe is the sym6 up/down round trip: near-identity, not exact
+    x = fill.hash_tensor((4, 3, 32, 32), "aug.identity.x", 1.0)
+    lab = torch.from_numpy(g["identity.labels"])
+    assert float(lab[:, 1:].abs().max()) == 0                      # only the x-flip (gate multiplier 1e8: a fair coin) fires
+    xf = torch.where(lab[:, 0].reshape(-1, 1, 1, 1) == 1, x.flip(3), x)
+    assert float((torch.from_numpy(g["identity.images"]) - xf).abs().max()) < 0.15
