@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
         hip.build()
     lib = hip.lib()
     header = open(os.path.join(ROOT, "include", "adm_hip.h")).read()
-    declared = sorted(set(re.findall(r"^int\s+(adm_\w+)\s*\(", header, flags=re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|long)\s+(adm_\w+)\s*\(", header, flags=re.M)))
     assert len(declared) >= 30
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in adm_hip.h but not exported"
