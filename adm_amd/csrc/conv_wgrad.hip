@@ -26,6 +26,7 @@ namespace {
 struct WgradP {
   const float* x; const float* dy; float* dwp;
   int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes;
+  float* dbias;      // optional: dbias[co] += sum_p dY[p][co] (the conv's bias gradient), by the tap-0 / ci-tile-0 workgroups
 };
 
 constexpr int WLDS = 36;   // floats per LDS row: 32 pixels + 4 pad
@@ -80,6 +81,13 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
   }
 
   f32x4 ra[AI], rb[BI];
+  // bias gradient = column sums of dY: the workgroups of the first Cin tile and first tap already stream every dY
+  // element of their Cout rows through registers, so they keep running sums (16 v_add per 32-pixel stage, on 1 in
+  // tilesN * taps workgroups) instead of a separate pass over dY
+  const bool do_bias = p.dbias != nullptr && tn == 0 && tap == 0;
+  f32x4 bsum[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto load_stage = [&](int s) {
     const int pb = pbeg + (s << 5);
     const bool full = pb + 32 <= pend;          // wave-uniform: only a ragged last stage needs per-row tests
@@ -130,6 +138,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
     }
   };
   auto store_stage = [&](int buf) {        // transpose: channel rows, pixel columns
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) bsum[i] += ra[i];
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i)
 #pragma unroll
@@ -175,6 +187,22 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
     __syncthreads();
   }
 
+  if (do_bias) {
+    // instructions i and i^1 of a wave cover the two 16-pixel halves of the same channel quad; lanes lk = 0..15 of a
+    // quad group hold different pixels
+#pragma unroll
+    for (int i = 0; i < AI; i += 2) {
+      f32x4 v = bsum[i] + bsum[i + 1];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], o, 64);
+      if (lk == 0 && co0 + a_row[i] < p.Cout) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&p.dbias[co0 + a_row[i] + j], v[j]);
+      }
+    }
+  }
   const int taps = p.ks * p.ks;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -211,12 +239,17 @@ int launch_wgrad(WgradP p, int splits, hipStream_t st) {
 
 extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
                               int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
+  return adm_conv_wgrad_bias(x, dy, dwp, nullptr, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, stream);
+}
+
+extern "C" int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
+                                   int ldx, int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
   if (!x || !dy || !dwp || B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3) || (ks != 1 && ks != 3)) return ADM_EINVAL;
   if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
   if (((uintptr_t)x | (uintptr_t)dy) & 15) return ADM_EINVAL;
   WgradP p;
-  p.x = x; p.dy = dy; p.dwp = dwp;
+  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
   p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.ks = ks; p.up = up; p.tilesN = 0;
   const long xb = (long)B * p.Hin * p.Win * ldx * 4, db = (long)p.P * lddy * 4;

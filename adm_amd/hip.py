@@ -24,6 +24,7 @@ _SIGS = {
     "adm_conv_fwd_ws": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_strided": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_bias": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_f32_to_bf16": [P, P, L, P],

@@ -134,7 +134,7 @@ def invalidate_packed():
 # Registry of live packed parameters, so that the optimiser can refresh ALL packed operands with one launch
 # (adm_pack_weight_table) instead of two small launches per layer on first use after every step.
 _pack_registry: dict = {}
-_pack_table = None          # (device int64 table, [entries], max_total)
+_pack_table = None          # (device int64 table, [entries], total 32x32 tiles, host rows)
 
 
 def repack_all():
@@ -143,7 +143,7 @@ def repack_all():
     global _pack_table, _pack_epoch
     _pack_epoch += 1
     if _pack_table is None:
-        rows, ents = [], []
+        rows, ents, tiles = [], [], 0
         for key, (wref, bref, ks, qkv) in list(_pack_registry.items()):
             w = wref()
             ent = getattr(w, "_adm_packed", None) if w is not None else None
@@ -152,20 +152,20 @@ def repack_all():
                 continue
             co, ci = w.shape[0], w.shape[1]
             cop, cip = ceil32(co), ceil32(ci)
-            rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv),
-                         cop * ks * ks * cip])
+            rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv), tiles])
+            tiles += (cop // 32) * (cip // 32)         # column 9 = exclusive prefix sum of 32x32 tiles
             ents.append((wref, bref, ks, qkv, ent))
         if not rows:
             return
         dev = ents[0][0]().device
-        _pack_table = (torch.tensor(rows, dtype=torch.int64, device=dev), ents, max(r[9] for r in rows), rows)
-    table, ents, max_total, rows = _pack_table
+        _pack_table = (torch.tensor(rows, dtype=torch.int64, device=dev), ents, tiles, rows)
+    table, ents, total_tiles, rows = _pack_table
     for (wref, bref, ks, qkv, ent), row in zip(ents, rows):      # storage moved or parameter died -> rebuild lazily
         w = wref()
         if w is None or w.data_ptr() != row[0] or getattr(w, "_adm_packed", None) is not ent:
             _pack_table = None
             return
-    call("adm_pack_weight_table", ptr(table), len(ents), max_total)
+    call("adm_pack_weight_table", ptr(table), len(ents), total_tiles)
     for wref, bref, ks, qkv, ent in ents:
         w = wref()
         b = bref() if bref is not None else None
@@ -297,18 +297,41 @@ class _Conv(torch.autograd.Function):
 
         def weight_and_bias_grads():
             nonlocal dw, db
+            fused_b = False
             if ctx.needs_input_grad[1]:
                 dwp = _new((cop, ks * ks * cip), dy)
+                # fp32: the weight-gradient kernel also produces the bias gradient (column sums of dy) on its way
+                dbp = None
+                if need_b and not bf16:
+                    fused_b = True
+                    if not qkv and cop == co:
+                        if bsink is not None:
+                            dbp = bsink                       # accumulate straight into the flat gradient buffer
+                        else:
+                            db = torch.zeros((co,), device=dy.device, dtype=_f32)
+                            dbp = db
+                    else:
+                        dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"wgrad P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
-                    call("adm_conv_wgrad_bf16" if bf16 else "adm_conv_wgrad", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip,
-                         cip, cop, cop, ks, int(up), 0)
+                    if bf16:
+                        call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+                    else:
+                        call("adm_conv_wgrad_bias", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, ks,
+                             int(up), 0)
+                if fused_b:
+                    if not qkv and cop == co:
+                        if bsink is not None:
+                            _notify(bias)
+                    else:
+                        db = _new((co,), dy)
+                        call("adm_permute_vec", ptr(dbp), ptr(db), co, co, int(qkv), 1)
                 if wsink is not None:
                     call("adm_unpack_wgrad", ptr(dwp), ptr(wsink), co, ci, ks, cop, cip, int(qkv), 1)
                     _notify(weight)
                 else:
                     dw = torch.empty_like(weight)
                     call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, int(qkv), 0)
-            if need_b:
+            if need_b and not fused_b:
                 if not qkv and cop == co:
                     if bsink is not None:
                         call("adm_colsum", ptr(dy), ptr(bsink), B * Ho * Wo, cop, cop, 1)

@@ -63,6 +63,12 @@ int adm_conv_fwd_ws(const float* x, const float* wp, const float* bias, const fl
 int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
                    int Cout, int lddy, int ks, int up, int splits, hipStream_t stream);
 
+/* adm_conv_wgrad that also accumulates the conv's bias gradient, dbias[co] += sum_pixels dy[p][co] (fp32 atomics; the
+ * caller zero-fills or passes the gradient buffer to accumulate into): the dy tiles already pass through registers, so
+ * no separate reduction pass over dy is needed.  dbias == NULL is adm_conv_wgrad. */
+int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx,
+                        int Cout, int lddy, int ks, int up, int splits, hipStream_t stream);
+
 /* ---- reduced-precision option (BASELINE.json configs[2], "bf16"): same contracts as adm_conv_fwd / adm_conv_wgrad,
  * tensors stay fp32 in HBM, the contraction runs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 on their way
  * into LDS, fp32 accumulation).  wp16 = the adm_pack_weight layouts converted with adm_f32_to_bf16.  Cin % 64 == 0
@@ -83,9 +89,9 @@ int adm_f32_to_bf16(const float* src, unsigned short* dst, long n, hipStream_t s
 int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci, int ks, int Co_pad, int Ci_pad,
                     int qkv, hipStream_t stream);
 /* adm_pack_weight for every layer of a model in ONE launch (used after each optimiser step).  table = device array of
- * n_entries rows of 10 int64: {src, dst_fwd, dst_bwd, Co, Ci, ks*ks, Co_pad, Ci_pad, qkv, Co_pad*ks*ks*Ci_pad};
- * max_total = the largest last column. */
-int adm_pack_weight_table(const long* table, int n_entries, long max_total, hipStream_t stream);
+ * n_entries rows of 10 int64: {src, dst_fwd, dst_bwd, Co, Ci, ks*ks, Co_pad, Ci_pad, qkv, tile_begin}, tile_begin = the
+ * exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) in row order; total_tiles = the sum.  Both outputs are required. */
+int adm_pack_weight_table(const long* table, int n_entries, long total_tiles, hipStream_t stream);
 /* inverse of the fwd packing for gradients: dw OIHW = (accumulate ? dw : 0) + dwp */
 int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
                      int accumulate, hipStream_t stream);

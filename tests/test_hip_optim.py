@@ -111,3 +111,33 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     # the EMA trails the weights but has moved away from the initial copy
     assert float((opt.ema - flat.flat).abs().max()) > 0
+
+
+def test_table_repack_equals_per_layer_pack():
+    """repack_all() (one tiled launch over every layer, run after each optimiser step) must reproduce adm_pack_weight's
+    operands bit for bit for every registered parameter: 3x3 / 1x1 convs, Linears, the 3-channel stem (Ci padded to 32),
+    the 3-channel heads (Co padded) and the qkv convs (row permutation)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import ops
+    from adm_amd.hip import call, ptr
+    gpu = torch.device("cuda:0")
+    m = _model(gpu)
+    _loss(m, gpu).backward()                       # populates the packed-operand cache for every layer
+    ents = [(w(), ks, qkv) for w, _b, ks, qkv in ops._pack_registry.values() if w() is not None and w().is_cuda]
+    mine = [(w, ks, qkv) for (w, ks, qkv) in ents if any(w is p for p in m.parameters())]
+    assert len(mine) > 50
+    with torch.no_grad():
+        for w, _, _ in mine:                       # rewrite the weights behind the cache's back (as the fused optimiser does)
+            w.view(-1).copy_(fill.hash_tensor((w.numel(),), "repack", 0.3).to(gpu))
+    ops.repack_all()
+    kinds = set()
+    for w, ks, qkv in mine:
+        ent = w._adm_packed
+        co, ci = w.shape[0], w.shape[1]
+        cop, cip = ops.ceil32(co), ops.ceil32(ci)
+        f, b = torch.empty_like(ent.fwd), torch.empty_like(ent.bwd)
+        call("adm_pack_weight", ptr(w.detach()), ptr(f), ptr(b), co, ci, ks, cop, cip, int(qkv))
+        assert torch.equal(f, ent.fwd) and torch.equal(b, ent.bwd), (tuple(w.shape), ks, qkv)
+        kinds.add((ks, bool(qkv), cop != co, cip != ci))
+    assert {(3, False, False, True), (3, False, True, False), (1, True, False, False), (1, False, False, False)} <= kinds
