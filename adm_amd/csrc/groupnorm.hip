@@ -24,6 +24,7 @@ __global__ void gn_partial_kernel(const float* __restrict__ x, double* __restric
   const int hw0 = s * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
   const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
   f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+#pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
     f32x4 v = xb[(long)hw * C4 + cq];
     s1 += v;
@@ -87,6 +88,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
   const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
   f32x4* yb = reinterpret_cast<f32x4*>(y + (long)b * HW * C);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
     f32x4 v = xb[(long)hw * C4 + cq];
     f32x4 u = v * ca + cb;
@@ -94,11 +96,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
 #pragma unroll
       for (int k = 0; k < 4; ++k) u[k] = silu_f(u[k]);
     }
-    if (drop_p > 0.f) {
-      uint64_t e0 = ((uint64_t)b * HW + hw) * C + cq * 4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) u[k] *= dropout_keep_scale(seed, e0 + k, drop_p, inv_keep);
-    }
+    if (drop_p > 0.f) u *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + cq, drop_p, inv_keep);
     yb[(long)hw * C4 + cq] = u;
   }
 }
@@ -131,15 +129,12 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ x, const float* 
   const f32x4* gb = reinterpret_cast<const f32x4*>(dy + (long)b * HW * C);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   f32x4 r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+#pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
     f32x4 v = xb[(long)hw * C4 + cq];
     f32x4 d = gb[(long)hw * C4 + cq];
     f32x4 u = v * ca + cb;
-    if (drop_p > 0.f) {
-      uint64_t e0 = ((uint64_t)b * HW + hw) * C + cq * 4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) d[k] *= dropout_keep_scale(seed, e0 + k, drop_p, inv_keep);
-    }
+    if (drop_p > 0.f) d *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + cq, drop_p, inv_keep);
     if (silu) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] *= silu_grad_f(u[k]);
@@ -248,21 +243,210 @@ __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __res
   const f32x4* gb = reinterpret_cast<const f32x4*>(dy + (long)b * HW * C);
   f32x4* ob = reinterpret_cast<f32x4*>(dx + (long)b * HW * C);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
     f32x4 v = xb[(long)hw * C4 + cq];
     f32x4 d = gb[(long)hw * C4 + cq];
     f32x4 u = v * ca + cb;
-    if (drop_p > 0.f) {
-      uint64_t e0 = ((uint64_t)b * HW + hw) * C + cq * 4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) d[k] *= dropout_keep_scale(seed, e0 + k, drop_p, inv_keep);
-    }
+    if (drop_p > 0.f) d *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + cq, drop_p, inv_keep);
     if (silu) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] *= silu_grad_f(u[k]);
     }
     ob[(long)hw * C4 + cq] = cg * d - c1 - ((v - cm) * cr) * c2;
   }
+}
+
+// ---------------------------------------------------------------- small feature maps: one launch per direction
+// For HW <= 256 the three (forward) / four (backward) launches above are latency-bound (0.5-1.8 TB/s measured at the
+// 4x4 and 8x8 levels).  Here one workgroup owns (image, chunk of WHOLE groups) and keeps its slab in REGISTERS between
+// the reduction and the apply pass: x (and dy) are read from HBM exactly once, and there is a single launch.
+// Thread map as above restricted to the chunk: Cc4 = Cc/4 quads, R = blockDim / Cc4 rows in flight, each thread owns
+// rows ry, ry + R, ... (<= MAXR of them).  Reductions keep the fixed summation order of the multi-launch path
+// (deterministic), with the same fp64 group combine.
+template <int MAXR>
+__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ ss,
+                                                           long ss_bstride, float* __restrict__ y,
+                                                           float* __restrict__ stats, int HW, int C, int G, int Cc,
+                                                           float eps, int silu, float drop_p, uint64_t seed) {
+  extern __shared__ float sm[];                    // [R][Cc][2] partials | [Gc][2] mean, rstd
+  const int Cc4 = Cc >> 2, R = blockDim.x / Cc4, C4 = C >> 2;
+  const int cq = threadIdx.x % Cc4, ry = threadIdx.x / Cc4;
+  const int b = blockIdx.x, c0 = blockIdx.y * Cc;
+  const int cpg = C / G, Gc = Cc / cpg, g0 = c0 / cpg;
+  const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C + c0);
+  f32x4 v[MAXR];
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int hw = ry + i * R;
+    v[i] = f32x4{0, 0, 0, 0};
+    if (hw < HW) v[i] = xb[(long)hw * C4 + cq];
+  }
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+  float* p1 = sm + (ry * Cc + cq * 4) * 2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { p1[2 * k] = s1[k]; p1[2 * k + 1] = s2[k]; }
+  __syncthreads();
+  float* gs = sm + R * Cc * 2;
+  if ((int)threadIdx.x < Gc) {
+    const int g = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int r = 0; r < R; ++r)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        a += (double)sm[(r * Cc + c) * 2];
+        q += (double)sm[(r * Cc + c) * 2 + 1];
+      }
+    const double inv_n = 1.0 / ((double)HW * cpg);
+    const double mean = a * inv_n;
+    double var = q * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
+    gs[2 * g] = m; gs[2 * g + 1] = rs;
+    stats[((long)b * G + g0 + g) * 2] = m;
+    stats[((long)b * G + g0 + g) * 2 + 1] = rs;
+  }
+  __syncthreads();
+  f32x4 ca, cb;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cl = cq * 4 + k, c = c0 + cl, g = cl / cpg;
+    const float mean = gs[2 * g], rstd = gs[2 * g + 1];
+    float sc1 = 1.f, sh = 0.f;
+    if (ss) { sc1 = 1.f + ss[b * ss_bstride + c]; sh = ss[b * ss_bstride + C + c]; }
+    const float ga = gamma[c] * rstd;
+    ca[k] = ga * sc1;
+    cb[k] = (beta[c] - mean * ga) * sc1 + sh;
+  }
+  f32x4* yb = reinterpret_cast<f32x4*>(y + (long)b * HW * C + c0);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int hw = ry + i * R;
+    if (hw >= HW) continue;
+    f32x4 u = v[i] * ca + cb;
+    if (silu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = silu_f(u[k]);
+    }
+    if (drop_p > 0.f) u *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + (c0 >> 2) + cq, drop_p, inv_keep);
+    yb[(long)hw * C4 + cq] = u;
+  }
+}
+
+template <int MAXR>
+__global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ ss,
+                                                           long ss_bstride, float* __restrict__ dx, float* __restrict__ tot,
+                                                           float* __restrict__ dss, int HW, int C, int G, int Cc, int silu,
+                                                           float drop_p, uint64_t seed) {
+  extern __shared__ float sm[];                    // [R][Cc][2] partials | [Cc][2] gamma' R1, gamma' R2 | [Gc][2] m1, m2
+  const int Cc4 = Cc >> 2, R = blockDim.x / Cc4, C4 = C >> 2;
+  const int cq = threadIdx.x % Cc4, ry = threadIdx.x / Cc4;
+  const int b = blockIdx.x, c0 = blockIdx.y * Cc;
+  const int cpg = C / G, Gc = Cc / cpg, g0 = c0 / cpg;
+  f32x4 ca, cb, cm, cr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + cq * 4 + k, g = c / cpg;
+    const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    float sc1 = 1.f, sh = 0.f;
+    if (ss) { sc1 = 1.f + ss[b * ss_bstride + c]; sh = ss[b * ss_bstride + C + c]; }
+    const float ga = gamma[c] * rstd;
+    ca[k] = ga * sc1;
+    cb[k] = (beta[c] - mean * ga) * sc1 + sh;
+    cm[k] = mean; cr[k] = rstd;
+  }
+  const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C + c0);
+  const f32x4* gb = reinterpret_cast<const f32x4*>(dy + (long)b * HW * C + c0);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  f32x4 xh[MAXR], d[MAXR];                         // xhat and du = dy * mask * act'(u), kept for the second pass
+  f32x4 r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int hw = ry + i * R;
+    xh[i] = f32x4{0, 0, 0, 0}; d[i] = f32x4{0, 0, 0, 0};
+    if (hw < HW) { xh[i] = xb[(long)hw * C4 + cq]; d[i] = gb[(long)hw * C4 + cq]; }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int hw = ry + i * R;
+    if (hw >= HW) continue;
+    const f32x4 v = xh[i];
+    const f32x4 u = v * ca + cb;
+    f32x4 dd = d[i];
+    if (drop_p > 0.f) dd *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + (c0 >> 2) + cq, drop_p, inv_keep);
+    if (silu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dd[k] *= silu_grad_f(u[k]);
+    }
+    xh[i] = (v - cm) * cr;
+    d[i] = dd;
+    r1 += dd;
+    r2 += dd * xh[i];
+  }
+  float* p1 = sm + (ry * Cc + cq * 4) * 2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { p1[2 * k] = r1[k]; p1[2 * k + 1] = r2[k]; }
+  __syncthreads();
+  float* ct = sm + R * Cc * 2;                     // [Cc][2]
+  float* gmv = ct + Cc * 2;                        // [Gc][2]
+  for (int cl = threadIdx.x; cl < Cc; cl += blockDim.x) {
+    float R1 = 0.f, R2 = 0.f;
+    for (int r = 0; r < R; ++r) { R1 += sm[(r * Cc + cl) * 2]; R2 += sm[(r * Cc + cl) * 2 + 1]; }
+    const int c = c0 + cl;
+    tot[((long)b * C + c) * 2] = R1;
+    tot[((long)b * C + c) * 2 + 1] = R2;
+    const float sc1 = ss ? 1.f + ss[b * ss_bstride + c] : 1.f;
+    const float gp = gamma[c] * sc1;
+    ct[2 * cl] = gp * R1;
+    ct[2 * cl + 1] = gp * R2;
+    if (dss) {
+      dss[(long)b * 2 * C + c] = gamma[c] * R2 + beta[c] * R1;
+      dss[(long)b * 2 * C + C + c] = R1;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < Gc) {
+    const int g = threadIdx.x;
+    const float inv_n = 1.f / ((float)HW * (float)cpg);
+    float a = 0.f, q = 0.f;
+    for (int cl = g * cpg; cl < (g + 1) * cpg; ++cl) { a += ct[2 * cl]; q += ct[2 * cl + 1]; }
+    gmv[2 * g] = a * inv_n; gmv[2 * g + 1] = q * inv_n;
+  }
+  __syncthreads();
+  f32x4 c1, c2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = (cq * 4 + k) / cpg;
+    c1[k] = cr[k] * gmv[2 * g];
+    c2[k] = cr[k] * gmv[2 * g + 1];
+  }
+  (void)g0;
+  f32x4* ob = reinterpret_cast<f32x4*>(dx + (long)b * HW * C + c0);
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int hw = ry + i * R;
+    if (hw < HW) ob[(long)hw * C4 + cq] = ca * d[i] - c1 - xh[i] * c2;
+  }
+}
+
+// chunk width for the fused path: whole groups, quads not straddling groups, <= 128 channels, <= 14 rows per thread
+inline int gn_fused_chunk(int HW, int C, int G) {
+  const int cpg = C / G;
+  if (HW > 256 || (cpg & 3)) return 0;
+  int best = 0;
+  for (int k = 1; k <= G; ++k) {
+    if (G % k) continue;
+    const int Cc = cpg * k;
+    if (Cc > 128) break;
+    const int R = 256 / (Cc / 4);
+    if (R >= 1 && (HW + R - 1) / R <= 14) best = Cc;
+  }
+  return best;
 }
 
 inline bool gn_shape_ok(int B, int HW, int C, int G) {
@@ -304,6 +488,34 @@ extern "C" int adm_gn_apply(const float* x, const float* stats, const float* gam
   return ADM_OK;
 }
 
+extern "C" int adm_gn_fwd(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+                          long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p,
+                          uint64_t seed, hipStream_t stream) {
+  if (!x || !stats || !ws || !gamma || !beta || !y || !gn_shape_ok(B, HW, C, G) || drop_p < 0.f || drop_p >= 1.f)
+    return ADM_EINVAL;
+  // forward: only up to 8x8 -- at 16x16 the 48-channel chunks (192-byte row segments) cost more than the saved pass
+  const int Cc = HW <= 64 ? gn_fused_chunk(HW, C, G) : 0;
+  if (Cc == 0) {
+    int rc = adm_gn_stats(x, stats, ws, B, HW, C, G, eps, stream);
+    if (rc != ADM_OK) return rc;
+    return adm_gn_apply(x, stats, gamma, beta, ss, ss_bstride, y, B, HW, C, G, silu, drop_p, seed, stream);
+  }
+  const int Cc4 = Cc / 4, R = 256 / Cc4, rows = (HW + R - 1) / R, Gc = Cc / (C / G);
+  const size_t smem = ((size_t)R * Cc * 2 + (size_t)Gc * 2) * sizeof(float);
+  const dim3 grid(B, C / Cc), block(Cc4 * R);
+  if (rows <= 2)
+    hipLaunchKernelGGL(gn_fused_fwd_kernel<2>, grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, HW, C, G,
+                       Cc, eps, silu, drop_p, seed);
+  else if (rows <= 8)
+    hipLaunchKernelGGL(gn_fused_fwd_kernel<8>, grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, HW, C, G,
+                       Cc, eps, silu, drop_p, seed);
+  else
+    hipLaunchKernelGGL(gn_fused_fwd_kernel<14>, grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, HW, C, G,
+                       Cc, eps, silu, drop_p, seed);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
 // red layout: part [B][S][C][2] | tot [B][C][2] | gm [B][G][2]   (floats)
 extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                           const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta,
@@ -315,6 +527,26 @@ extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, c
   float* part = red;
   float* tot = part + (long)B * S * C * 2;
   float* gm = tot + (long)B * C * 2;
+  const int Cc = gn_fused_chunk(HW, C, G);
+  if (Cc) {          // small feature map: one launch (+ the parameter-gradient reduction over the batch)
+    const int Cc4 = Cc / 4, Rf = 256 / Cc4, rws = (HW + Rf - 1) / Rf, Gc = Cc / (C / G);
+    const size_t smf = ((size_t)Rf * Cc * 2 + (size_t)Cc * 2 + (size_t)Gc * 2) * sizeof(float);
+    const dim3 grid(B, C / Cc), block(Cc4 * Rf);
+    if (rws <= 2)
+      hipLaunchKernelGGL(gn_fused_bwd_kernel<2>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, dx, tot,
+                         dss, HW, C, G, Cc, silu, drop_p, seed);
+    else if (rws <= 8)
+      hipLaunchKernelGGL(gn_fused_bwd_kernel<8>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, dx, tot,
+                         dss, HW, C, G, Cc, silu, drop_p, seed);
+    else
+      hipLaunchKernelGGL(gn_fused_bwd_kernel<14>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, dx,
+                         tot, dss, HW, C, G, Cc, silu, drop_p, seed);
+    if (dgamma)
+      hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(adm_cdiv(C, 32)), dim3(256), 0, stream, tot, ss, ss_bstride, dgamma,
+                         dbeta, B, C);
+    ADM_CHECK_LAUNCH();
+    return ADM_OK;
+  }
   size_t smem = (size_t)R * C * 2 * sizeof(float);
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(B, S), dim3(gn_threads(C)), smem, stream, x, dy, stats, gamma, beta,
                      ss, ss_bstride, part, HW, C, G, rows, silu, drop_p, seed);

@@ -403,7 +403,8 @@ class _GroupNormAct(torch.autograd.Function):
         S = hip.lib().adm_gn_splits(HW, C)
         stats = _new((B, G, 2), x)
         ws = _new((B * S * G * 2,), x, torch.float64)
-        call("adm_gn_stats", ptr(x), ptr(stats), ptr(ws), B, HW, C, G, float(eps))
+        prof = _Prof("gn", 12.0 * x.numel(), f"gn-fwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)")
+        prof.__enter__()
         ssc, bstride = None, 0
         if ss is not None:
             ssc = _chk(ss, "scale_shift")
@@ -411,8 +412,9 @@ class _GroupNormAct(torch.autograd.Function):
                 raise RuntimeError(f"scale/shift shape {tuple(ssc.shape)} does not match C={C}, B={B}")
             bstride = 0 if ssc.shape[0] == 1 else 2 * C
         y = torch.empty_like(x)
-        call("adm_gn_apply", ptr(x), ptr(stats), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), B, HW, C, G, int(silu),
-             float(drop_p), seed)
+        call("adm_gn_fwd", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), B, HW, C, G, float(eps),
+             int(silu), float(drop_p), seed)
+        prof.__exit__()
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (G, S, bstride, silu, drop_p, seed)
         return y
@@ -435,8 +437,9 @@ class _GroupNormAct(torch.autograd.Function):
         dgamma = sg if direct else torch.zeros_like(gamma)
         dbeta = sb if direct else torch.zeros_like(beta)
         red = _new((B * S * C * 2 + B * C * 2 + B * G * 2,), x)
-        call("adm_gn_bwd", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
-             ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
+        with _Prof("gn", 20.0 * x.numel(), f"gn-bwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)"):
+            call("adm_gn_bwd", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
+                 ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
         if direct:
             _notify(gamma); _notify(beta)
             return dx, None, None, dss, None, None, None, None, None

@@ -115,6 +115,11 @@ int adm_gn_stats(const float* x, float* stats, double* ws, int B, int HW, int C,
 int adm_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
                  long ss_bstride, float* y, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
                  hipStream_t stream);
+/* adm_gn_stats + adm_gn_apply in one call (same arguments); feature maps of HW <= 256 pixels run as ONE launch that keeps
+ * its slab in registers between the reduction and the apply pass (x is read once).  stats is written either way. */
+int adm_gn_fwd(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+               long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
+               hipStream_t stream);
 /* Backward of adm_gn_apply.  Pass 1 reduces per (b,c): r1 = sum du, r2 = sum du*xhat into red[B][C][2]
  * (du = dy * mask * act'(u)); pass 2 writes dx and, when the pointers are non-NULL, dss[B][2C]
  * (d scale | d shift), dgamma[C], dbeta[C] (accumulated: caller zero-fills dgamma/dbeta). */
