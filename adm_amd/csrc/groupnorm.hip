@@ -217,8 +217,9 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
 __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                  const float* __restrict__ stats, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ ss, long ss_bstride,
-                                 const float* __restrict__ gm, float* __restrict__ dx, int HW, int C, int G,
-                                 int rows_per_split, int silu, float drop_p, uint64_t seed) {
+                                 const float* __restrict__ gm, const float* __restrict__ addend,
+                                 float* __restrict__ dx, int HW, int C, int G, int rows_per_split, int silu, float drop_p,
+                                 uint64_t seed) {
   const int C4 = C >> 2, R = blockDim.x / C4;
   const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
   const int b = blockIdx.x;
@@ -242,18 +243,21 @@ __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __res
   const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
   const f32x4* gb = reinterpret_cast<const f32x4*>(dy + (long)b * HW * C);
   f32x4* ob = reinterpret_cast<f32x4*>(dx + (long)b * HW * C);
+  const f32x4* ab = addend ? reinterpret_cast<const f32x4*>(addend + (long)b * HW * C) : nullptr;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 #pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
     f32x4 v = xb[(long)hw * C4 + cq];
     f32x4 d = gb[(long)hw * C4 + cq];
+    f32x4 extra = {0, 0, 0, 0};
+    if (ab) extra = ab[(long)hw * C4 + cq];
     f32x4 u = v * ca + cb;
     if (drop_p > 0.f) d *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + cq, drop_p, inv_keep);
     if (silu) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] *= silu_grad_f(u[k]);
     }
-    ob[(long)hw * C4 + cq] = cg * d - c1 - ((v - cm) * cr) * c2;
+    ob[(long)hw * C4 + cq] = cg * d - c1 - ((v - cm) * cr) * c2 + extra;
   }
 }
 
@@ -340,7 +344,8 @@ template <int MAXR>
 __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
-                                                           long ss_bstride, float* __restrict__ dx, float* __restrict__ tot,
+                                                           long ss_bstride, const float* __restrict__ addend,
+                                                           float* __restrict__ dx, float* __restrict__ tot,
                                                            float* __restrict__ dss, int HW, int C, int G, int Cc, int silu,
                                                            float drop_p, uint64_t seed) {
   extern __shared__ float sm[];                    // [R][Cc][2] partials | [Cc][2] gamma' R1, gamma' R2 | [Gc][2] m1, m2
@@ -427,10 +432,14 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
   }
   (void)g0;
   f32x4* ob = reinterpret_cast<f32x4*>(dx + (long)b * HW * C + c0);
+  const f32x4* ab = addend ? reinterpret_cast<const f32x4*>(addend + (long)b * HW * C + c0) : nullptr;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
     const int hw = ry + i * R;
-    if (hw < HW) ob[(long)hw * C4 + cq] = ca * d[i] - c1 - xh[i] * c2;
+    if (hw >= HW) continue;
+    f32x4 o = ca * d[i] - c1 - xh[i] * c2;
+    if (ab) o += ab[(long)hw * C4 + cq];
+    ob[(long)hw * C4 + cq] = o;
   }
 }
 
@@ -521,6 +530,14 @@ extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, c
                           const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta,
                           float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
                           hipStream_t stream) {
+  return adm_gn_bwd_add(x, dy, stats, gamma, beta, ss, ss_bstride, nullptr, dx, dss, dgamma, dbeta, red, B, HW, C, G, silu,
+                        drop_p, seed, stream);
+}
+
+extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                              const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma,
+                              float* dbeta, float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
+                              hipStream_t stream) {
   if (!x || !dy || !stats || !gamma || !beta || !dx || !red || !gn_shape_ok(B, HW, C, G)) return ADM_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return ADM_EINVAL;
   int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S), R = gn_rows_par(C);
@@ -533,13 +550,13 @@ extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, c
     const size_t smf = ((size_t)Rf * Cc * 2 + (size_t)Cc * 2 + (size_t)Gc * 2) * sizeof(float);
     const dim3 grid(B, C / Cc), block(Cc4 * Rf);
     if (rws <= 2)
-      hipLaunchKernelGGL(gn_fused_bwd_kernel<2>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, dx, tot,
+      hipLaunchKernelGGL(gn_fused_bwd_kernel<2>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx, tot,
                          dss, HW, C, G, Cc, silu, drop_p, seed);
     else if (rws <= 8)
-      hipLaunchKernelGGL(gn_fused_bwd_kernel<8>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, dx, tot,
+      hipLaunchKernelGGL(gn_fused_bwd_kernel<8>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx, tot,
                          dss, HW, C, G, Cc, silu, drop_p, seed);
     else
-      hipLaunchKernelGGL(gn_fused_bwd_kernel<14>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, dx,
+      hipLaunchKernelGGL(gn_fused_bwd_kernel<14>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx,
                          tot, dss, HW, C, G, Cc, silu, drop_p, seed);
     if (dgamma)
       hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(adm_cdiv(C, 32)), dim3(256), 0, stream, tot, ss, ss_bstride, dgamma,
@@ -556,7 +573,7 @@ extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, c
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(adm_cdiv(C, 32)), dim3(256), 0, stream, tot, ss, ss_bstride, dgamma,
                        dbeta, B, C);
   hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(B, S), dim3(gn_threads(C)), 0, stream, x, dy, stats, gamma, beta, ss,
-                     ss_bstride, gm, dx, HW, C, G, rows, silu, drop_p, seed);
+                     ss_bstride, gm, addend, dx, HW, C, G, rows, silu, drop_p, seed);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -38,6 +38,7 @@ _SIGS = {
     "adm_gn_apply": [P, P, P, P, P, L, P, I, I, I, I, I, F, U, P],
     "adm_gn_fwd": [P, P, P, P, P, P, L, P, I, I, I, I, F, I, F, U, P],
     "adm_gn_bwd": [P, P, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, F, U, P],
+    "adm_gn_bwd_add": [P, P, P, P, P, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P],
     "adm_softmax_rows": [P, L, I, L, F, P],
     "adm_posterior_sample": [P, I, P, P, I, L, I, F, P],
     "adm_attn_fwd": [P, P, P, I, I, I, P],

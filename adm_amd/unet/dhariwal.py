@@ -96,6 +96,11 @@ class GroupNorm(nn.Module):
         seed = ops.next_dropout_seed() if drop_p > 0 else 0
         return ops.group_norm_act(x, self.weight, self.bias, scale_shift, silu=silu, drop_p=drop_p, seed=seed)
 
+    def fork(self, x, silu=False):
+        """(norm(x), x): x comes back for the residual branch so that both gradients are summed inside the GroupNorm
+        backward kernel (ops.group_norm_act_fork)."""
+        return ops.group_norm_act_fork(x, self.weight, self.bias, None, silu=silu)
+
 
 class UNetBlock(nn.Module):
     def __init__(self, in_channels, out_channels, emb_channels, up=False, down=False, attention=False, num_heads=None,
@@ -124,12 +129,14 @@ class UNetBlock(nn.Module):
             self.proj = Conv2d(out_channels, out_channels, 1, **init_zero)
 
     def forward(self, x, emb):
-        h = self.conv0(self.norm0(x, silu=True))
+        n0, x = self.norm0.fork(x, silu=True)         # x feeds the normalised branch AND the residual / skip branch
+        h = self.conv0(n0)
         p = self.dropout if self.training else 0.0
         h = self.norm1(h, self.affine(emb), silu=True, drop_p=p)
         h = self.conv1(h, residual=x if self.skip is None else self.skip(x))
         if self.num_heads:
-            a = ops.attention(self.qkv(self.norm2(h)), self.num_heads)
+            n2, h = self.norm2.fork(h)
+            a = ops.attention(self.qkv(n2), self.num_heads)
             h = self.proj(a, residual=h)
         return h
 

@@ -127,6 +127,13 @@ int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float*
                const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta, float* red,
                int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);
 
+/* adm_gn_bwd with dx = (GroupNorm input gradient) + addend[B][HW][C] (addend may be NULL): the block input also feeds the
+ * residual branch (uncond_unet.py:189, 201), and adding that branch's gradient here saves autograd's separate
+ * read-read-write pass over the activation. */
+int adm_gn_bwd_add(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                   const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma, float* dbeta,
+                   float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);
+
 /* ---------------- KL autoencoder (first stage) helpers ---------------------------------------- */
 
 /* In-place s[r][0:cols] = softmax(scale * s[r][0:cols]) for `rows` rows of stride ld: the single-head
