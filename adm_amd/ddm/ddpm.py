@@ -177,6 +177,36 @@ class DDPMBase(nn.Module):
         return loss, log
 
     # ------------------------------------------------------------------ sampling
+    def _use_graph(self) -> bool:
+        """HIP-graph replay of the sampler's UNet forward (cfg key ``sample_graph`` or ADM_SAMPLE_GRAPH=1).  The forward
+        is ~900 launches; at small batch they are launch-bound and a graph removes the per-launch host cost."""
+        import os
+        return bool(_cfg_get(self.cfg, "sample_graph", False)) or os.environ.get("ADM_SAMPLE_GRAPH", "0") == "1"
+
+    def _sampling_graph(self, shape, dev):
+        """Capture (once per shape and weight version) ``C, noise = model(x_static, t_static)``.  Everything inside is
+        device-side and allocation-free at the C-ABI level (torch's capture-time allocations come from the graph's private
+        pool), so the capture is legal; the fp64 state update stays outside (its t values are host scalars)."""
+        from .. import ops
+        cache = self.__dict__.setdefault("_graphs", {})
+        key = (shape, str(dev))
+        ent = cache.get(key)
+        if ent is not None and ent["epoch"] == ops._pack_epoch and not self.training:
+            return ent
+        x = torch.zeros(shape, dtype=torch.float64, device=dev)
+        t = torch.ones((), dtype=torch.float64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):              # warm-up: packs weights, sets kernel attributes, fills allocator pools
+            self.model(x, t)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            C, noise = self.model(x, t)
+        ent = {"graph": graph, "x": x, "t": t, "C": C, "noise": noise, "epoch": ops._pack_epoch}
+        cache[key] = ent
+        return ent
+
     def t_steps(self):
         n = self.sampling_timesteps
         i = torch.arange(n, dtype=torch.float64)
@@ -209,9 +239,18 @@ class DDPMBase(nn.Module):
         clip = self.clip_x_start and self.SCHEDULE == "const"     # const_2's deterministic sampler never clamps x0
         traj = []
         n = len(ts) - 1
+        g = self._sampling_graph(tuple(shape), dev) if self._use_graph() else None
+        if g is not None:           # the UNet forward replays from a captured HIP graph on static buffers
+            g["x"].copy_(x)
+            x = g["x"]
         for i in range(n):
             t_cur, t_next = float(ts[i]), float(ts[i + 1])
-            C, noise = self.model(x, torch.tensor(t_cur, dtype=torch.float64, device=dev))
+            if g is not None:
+                g["t"].fill_(t_cur)
+                g["graph"].replay()
+                C, noise = g["C"], g["noise"]
+            else:
+                C, noise = self.model(x, torch.tensor(t_cur, dtype=torch.float64, device=dev))
             last = unnormalize and i == n - 1
             if return_traj and last:   # trajectory holds the pre-normalisation state
                 xc = x.clone()

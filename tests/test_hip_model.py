@@ -276,3 +276,27 @@ def test_latent_unet_with_32x32_attention_vs_oracle(gpu):
         if err > 2e-3:
             bad.append((name, err))
     assert not bad, bad[:10]
+
+
+def test_sampler_hip_graph_replay_equals_eager(gpu, monkeypatch):
+    """ADM_SAMPLE_GRAPH=1: the 10 UNet forwards replay from one captured HIP graph; results must be bit-identical to the
+    eager launches, also on a second call (cached graph) and after a weight update (graph re-captured)."""
+    from adm_amd.ddm.ddm_const import DDPM
+    from adm_amd import ops
+    m, cfg, sd = build_unet("uncond_unet", gpu)
+    mcfg = dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True)
+    dpm = DDPM(model=m, image_size=[32, 32], sampling_timesteps=10, perceptual_weight=0.0, cfg=mcfg).to(gpu).eval()
+    xT = fill.hash_tensor((3, 3, 32, 32), "xTg", 1.7, torch.float64).to(gpu)
+    eager = dpm.sample(batch_size=3, x_T=xT)
+    monkeypatch.setenv("ADM_SAMPLE_GRAPH", "1")
+    g1 = dpm.sample(batch_size=3, x_T=xT)
+    g2 = dpm.sample(batch_size=3, x_T=xT)
+    assert torch.equal(eager, g1) and torch.equal(eager, g2)
+    assert len(dpm._graphs) == 1
+    with torch.no_grad():
+        dict(dpm.named_parameters())["model.model.out_conv.weight"].mul_(1.5)
+    ops.invalidate_packed()
+    g3 = dpm.sample(batch_size=3, x_T=xT)
+    monkeypatch.setenv("ADM_SAMPLE_GRAPH", "0")
+    e3 = dpm.sample(batch_size=3, x_T=xT)
+    assert torch.equal(g3, e3) and not torch.equal(g3, eager)
