@@ -89,6 +89,7 @@ class BucketedGradReducer:
                     self.param_bucket[m] = b
                 end, count, members = cur_lo, 0, []
         self.pending = [0] * len(self.buckets)
+        self.seen = [False] * len(flat.params)
         self.enabled = True
         self.handles = []
         if self.active:
@@ -99,8 +100,13 @@ class BucketedGradReducer:
 
     def _make_hook(self, idx):
         def hook(_p):
-            if not self.enabled:
+            if not self.enabled or self.seen[idx]:
                 return
+            # once per parameter and step: a parameter whose gradient a HIP kernel accumulated directly is announced
+            # through _adm_grad_sink, and autograd may STILL fire its post-accumulate hook for the (undefined) gradient
+            # the backward returned -- counting both launched every bucket twice (harmless at world size 1, a doubled
+            # gradient sum at world size > 1)
+            self.seen[idx] = True
             b = self.param_bucket[idx]
             self.pending[b] += 1
             if self.pending[b] == self.buckets[b][2]:
@@ -133,6 +139,7 @@ class BucketedGradReducer:
                 torch.cuda.current_stream().wait_stream(self.side)
         self.handles = []
         self.pending = [0] * len(self.buckets)
+        self.seen = [False] * len(self.flat.params)
 
 
 class FusedAdamWEMA:
