@@ -153,7 +153,7 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("ADM_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -162,7 +162,13 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" IS RCCL on ROCm.  ADM_DIST_BACKEND=gloo exists for tests that rehearse N ranks on ONE card (two RCCL
+        # ranks cannot share a device); ADM_LOCAL_DEVICE pins every rank to that card.
+        backend = os.environ.get("ADM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from adm_amd import hip, ops
     from adm_amd.optim import BucketedGradReducer, FlatParams, FusedAdamWEMA, ema_decay_at, lr_lambda
@@ -224,10 +230,13 @@ def main():
     # ---- roofline of the dominant kernel: the fp32-MFMA implicit GEMM (fwd + dgrad launches) and wgrad ----
     roof = None
     sample_ips = None
+    # one more step with per-launch HIP events.  EVERY rank runs it (the step contains the gradient all-reduces: a step
+    # on rank 0 alone would wait for its peers forever); only rank 0 records and reports.
     if rank == 0:
         ops.PROFILE = []
-        train_step(args.warmup + args.steps)
-        torch.cuda.synchronize()
+    train_step(args.warmup + args.steps)
+    barrier()
+    if rank == 0:
         recs, ops.PROFILE = ops.PROFILE, None
         log(f"profiled step: {len(recs)} GEMM-shaped launches")
         by = {}

@@ -101,3 +101,52 @@ def test_two_rank_step_equals_single_rank_on_the_whole_batch(tmp_path):
     # 2*lr; compare in units of the step size instead of bitwise
     assert float((got["flat"] - want).abs().max()) <= 2.5e-3
     assert float((got["flat"] - want).abs().mean()) <= 2e-5
+
+
+def _torchrun(script_args, tmp_path, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, ADM_DIST_BACKEND="gloo", ADM_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=root)
+
+
+def test_bench_two_ranks_prints_one_whole_job_line(tmp_path):
+    """bench.py under the driver's launch line with N=2 (gloo on one card): rank 0 prints exactly one JSON line whose
+    value is the whole-job rate (2 x per-rank batch / max-over-ranks time) and n_gpus = 2."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--small", "--batch", "8"], tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+    assert abs(out["value"] - 16 / (out["ms_per_step"] / 1e3)) <= 0.01 * out["value"]
+    assert out["sample_images_per_sec"] > 0 and "cpu_baseline" not in out
+    assert out["roofline"]["launches_per_step"] > 0
+
+
+def test_trainer_two_ranks_checkpoint(tmp_path):
+    """train_uncond_dpm.py with 2 ranks: global batch split, rank-0 checkpoint/EMA, both ranks finish."""
+    import yaml
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.load(open(os.path.join(root, "configs/cifar10/ddm_uncond_const_uncond_unet.yaml")), Loader=yaml.SafeLoader)
+    cfg["model"]["unet"].update(model_channels=64, num_blocks=1)
+    cfg["data"]["batch_size"] = 8
+    res = str(tmp_path / "run")
+    cfg["trainer"].update(results_folder=res, train_num_steps=2, save_and_sample_every=2, log_freq=1, test_before=False,
+                          gradient_accumulate_every=2, ema_update_after_step=0, ema_update_every=1)
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    r = _torchrun(["train_uncond_dpm.py", "--cfg", path], tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "[Train Step] 2/2" in r.stdout and "training complete" in r.stdout
+    ck = torch.load(os.path.join(res, "model-1.pt"), map_location="cpu", weights_only=True)
+    assert ck["step"] == 2 and "ema_model.model.model.enc.32x32_conv.weight" in ck["ema"]
+    assert os.path.exists(os.path.join(res, "sample-1.png"))

@@ -211,12 +211,16 @@ def build_model(model_cfg):
 def main(args):
     cfg = Cfg(args.cfg)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("ADM_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("ADM_DIST_BACKEND", "nccl")       # "nccl" = RCCL; gloo only for one-card rehearsals in tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     model_cfg = cfg.model
     dpm = build_model(model_cfg).to(device).train()
     global_batch = int(cfg.data.batch_size)
