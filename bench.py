@@ -253,13 +253,16 @@ def main():
         fl, ms, n = by.get("igemm", [0.0, 1e-9, 0])
         # HBM-side traffic per launch comes from rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
         # WRITE_SIZE runs, FETCH doubled per MI355X_MICROARCH.md): counters cannot be read from inside the process.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc_all = None, None, {}
         try:
             pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))[-1]
-            traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["igemm"]["traffic_bytes_per_launch"]
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", pmc)))
+            traffic = pmc_all["igemm"]["traffic_bytes_per_launch"]
             traffic_src = "profiles/" + pmc
         except Exception:
             pass
+        if args.dtype != "f32" or args.config != "cifar":
+            pmc_all = {}                             # the committed PMC passes are of the fp32 CIFAR run
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         if args.dtype != "f32":
             traffic, traffic_src = None, None       # the committed PMC passes are of the fp32 kernels
@@ -268,17 +271,23 @@ def main():
                 "achieved": round(fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl / ms / 1e9 / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes/launch (L2-miss side: HBM + Infinity Cache)", "traffic_source": traffic_src,
-                "algorithmic_flops_per_launch": round(fl / max(n, 1)), "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "ms_per_step_in_kernel": round(ms, 2)}
+                "algorithmic_flops_per_launch": round(fl / max(n, 1)), "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "ms_per_step_in_kernel": round(ms, 2),
+                "mfma_busy_pmc": pmc_all.get("igemm", {}).get("mfma_busy_fraction"),
+                "sustained_clock_GHz_pmc": pmc_all.get("igemm", {}).get("effective_clock_GHz")}
         if "wgrad" in by:
             fl2, ms2, n2 = by["wgrad"]
             roof["wgrad"] = {"kernel": "wgrad_f32_kernel", "achieved": round(fl2 / ms2 / 1e9, 2),
                              "frac": round(fl2 / ms2 / 1e9 / peak, 4), "launches_per_step": n2,
-                             "ms_per_step_in_kernel": round(ms2, 2)}
+                             "ms_per_step_in_kernel": round(ms2, 2),
+                             "mfma_busy_pmc": pmc_all.get("wgrad", {}).get("mfma_busy_fraction")}
         if "attn" in by:
             fl3, ms3, n3 = by["attn"]
             roof["attention"] = {"kernel": "attn_fwd/bwd kernels", "achieved": round(fl3 / ms3 / 1e9, 2),
                                  "frac": round(fl3 / ms3 / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": n3,
-                                 "ms_per_step_in_kernel": round(ms3, 2)}
+                                 "ms_per_step_in_kernel": round(ms3, 2),
+                                 "mfma_busy_pmc": pmc_all.get("attn", {}).get("mfma_busy_fraction"),
+                                 "note": "achieved/frac count ALGORITHMIC flops (the backward executes 7 products for 5); "
+                                         "mfma_busy_pmc is SQ_VALU_MFMA_BUSY_CYCLES over all SIMDs from the committed PMC pass"}
     # ---- 10-step sampling, every rank samples its own batch, no collectives ----
     if not args.no_sample:
         dpm.eval()
