@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
   const int shift = (dy_ * p.W + dx_) * p.ldx;                       // floats; may be negative (FAST path only)
   const __amdgpu_buffer_rsrc_t rs_xt =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, p.xbytes - shift * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, max(0, p.xbytes - shift * 4), 0x00020000);
+  // (a tap shift larger than the whole tensor -- 1 x 2 images -- must not wrap num_records around: 0 records = every
+  //  access out of range = zeros, which is what such a tap contributes)
 
   int a_pix[AI], a_row[AI], b_pix[BI], b_row[BI];     // stage-local pixel, tile-local first channel of the quad
   unsigned a_voff[AI], b_voff[BI], b_colb[BI];

@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBP p) {
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
   const int shift = (dy_ * p.W + dx_) * p.ldx;
   const __amdgpu_buffer_rsrc_t rs_xt =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, p.xbytes - shift * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, max(0, p.xbytes - shift * 4), 0x00020000);
+  // (a tap shift larger than the whole tensor -- 1 x 2 images -- must not wrap num_records around: 0 records = every
+  //  access out of range = zeros, which is what such a tap contributes)
 
   int a_pix[AU], a_row[AU], b_pix[BU], b_row[BU];        // first pixel of the pair (stage-local), first channel of the quad
   unsigned a_voff[AU], b_voff[BU][2], b_colb[BU];

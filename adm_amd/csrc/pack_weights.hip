@@ -100,24 +100,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
   }
 }
 
-// One launch for ALL layers of a model.  table[e] = {src, dst_fwd, dst_bwd, Co, Ci, taps, Co_pad, Ci_pad, qkv, tile_begin}
-// (int64 each; tile_begin = exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) over the rows, in row order).  One workgroup
-// per 32 (out-channel) x 32 (in-channel) tile of one layer: the tile's taps-interleaved source runs (32*taps contiguous
-// floats per out-channel) go through LDS once and leave as 128-byte row segments of BOTH operand layouts, so reads and
-// writes are coalesced (the previous element-per-thread gather ran at 0.7 TB/s and cost 3.8 ms per optimiser step).
+// One launch for ALL layers of a model.  table[e] = {src, dst_fwd, dst_bwd, Co, Ci, taps, Co_pad, Ci_pad, qkv, tile_begin,
+// dst_wino_fwd, dst_wino_bwd} (int64 each; tile_begin = exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) over the rows, in
+// row order; the two Winograd destinations are 0 for layers that do not use conv_wino.hip).  One workgroup per 32
+// (out-channel) x 32 (in-channel) tile of one layer: the tile's taps-interleaved source runs (32*taps contiguous floats per
+// out-channel) go through LDS once and leave as 128-byte row segments of every operand layout, so reads and writes are
+// coalesced (the previous element-per-thread gather ran at 0.7 TB/s and cost 3.8 ms per optimiser step).
+constexpr int PT_COLS = 12;
 __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict__ table, int n_entries) {
   __shared__ float tile[32][32 * 9 + 1];
   // layer of this tile: last row whose tile_begin <= blockIdx.x
   int lo = 0, hi = n_entries - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (table[(long)mid * 10 + 9] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (table[(long)mid * PT_COLS + 9] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  const long* t = table + (long)lo * 10;
+  const long* t = table + (long)lo * PT_COLS;
   const float* __restrict__ w = reinterpret_cast<const float*>(t[0]);
   float* __restrict__ fwd = reinterpret_cast<float*>(t[1]);
   float* __restrict__ bwd = reinterpret_cast<float*>(t[2]);
   const int Co = (int)t[3], Ci = (int)t[4], taps = (int)t[5], Co_pad = (int)t[6], Ci_pad = (int)t[7], qkv = (int)t[8];
+  float* __restrict__ wf = reinterpret_cast<float*>(t[10]);
+  float* __restrict__ wb = reinterpret_cast<float*>(t[11]);
   const int local = (int)((long)blockIdx.x - t[9]);
   const int tiles_ci = Ci_pad >> 5;
   const int co0 = (local / tiles_ci) << 5, ci0 = (local % tiles_ci) << 5;
@@ -140,6 +144,36 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
     const int co_l = e & 31, rest = e >> 5;
     const int tapf = rest % taps, ci_l = rest / taps;
     bwd[((long)(ci0 + ci_l) * taps + tapf) * Co_pad + co0 + co_l] = tile[co_l][ci_l * taps + (taps - 1 - tapf)];
+  }
+  if (taps != 9) return;
+  // Winograd F(2,3) operands (conv_wino.hip): G g per filter row, u = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
+  if (wf) {                                        // wf[xi][co][ky][ci]: ci fastest
+    const long plane = (long)Co_pad * 3 * Ci_pad;
+    for (int e = threadIdx.x; e < 32 * 3 * 32; e += 256) {
+      const int ci_l = e & 31, rest = e >> 5;
+      const int ky = rest % 3, co_l = rest / 3;
+      const float* g = &tile[co_l][ci_l * 9 + ky * 3];
+      const float g0 = g[0], g1 = g[1], g2 = g[2];
+      const long o = ((long)(co0 + co_l) * 3 + ky) * Ci_pad + ci0 + ci_l;
+      wf[o] = g0;
+      wf[o + plane] = (g0 + g1 + g2) * 0.5f;
+      wf[o + 2 * plane] = (g0 - g1 + g2) * 0.5f;
+      wf[o + 3 * plane] = g2;
+    }
+  }
+  if (wb) {                                        // wb[xi][ci][ky'][co]: co fastest; g'(ky', kx') = w(2-ky', 2-kx')
+    const long plane = (long)Ci_pad * 3 * Co_pad;
+    for (int e = threadIdx.x; e < 32 * 3 * 32; e += 256) {
+      const int co_l = e & 31, rest = e >> 5;
+      const int kyf = rest % 3, ci_l = rest / 3;
+      const float* g = &tile[co_l][ci_l * 9 + (2 - kyf) * 3];
+      const float g0 = g[2], g1 = g[1], g2 = g[0];
+      const long o = ((long)(ci0 + ci_l) * 3 + kyf) * Co_pad + co0 + co_l;
+      wb[o] = g0;
+      wb[o + plane] = (g0 + g1 + g2) * 0.5f;
+      wb[o + 2 * plane] = (g0 - g1 + g2) * 0.5f;
+      wb[o + 3 * plane] = g2;
+    }
   }
 }
 

@@ -10,6 +10,7 @@ Each Function's backward is hand-written HIP as well -- autograd is only the tap
 from __future__ import annotations
 
 import itertools
+import os
 import weakref
 from typing import Optional
 
@@ -60,12 +61,18 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 # packed-weight cache
 # ------------------------------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16")
+    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "src")
 
 
 # Contraction precision of the conv / Linear kernels: "f32" (default: exact fp32 MFMA) or "bf16" (BASELINE
 # configs[2]: bf16 MFMA operands, fp32 accumulation and storage).  Opt-in only; see set_compute_precision().
 COMPUTE = "f32"
+
+# 3x3 stride-1 convs (forward and data gradient) with M >= WINO_MIN_M output pixels and an even width run through the
+# 1-D Winograd F(2,3) kernel (adm_conv_fwd_wino: 1.5x fewer MFMA flops, fp32, error at the direct kernel's own rounding
+# level).  ADM_WINOGRAD=0 keeps every conv on the direct implicit GEMM.
+WINOGRAD = os.environ.get("ADM_WINOGRAD", "1") != "0"
+WINO_MIN_M = 8192
 
 
 def set_compute_precision(mode: str):
@@ -87,6 +94,20 @@ def _bf16_operand(ent: "_Packed", which: str) -> torch.Tensor:
     return t
 
 
+def _wino_operands(weight: torch.Tensor, ent: "_Packed"):
+    """Winograd operands (G g) of a packed 3x3 entry, built on first use; afterwards refreshed by repack_all()."""
+    if ent.wf is None:
+        global _pack_table
+        co, ci = weight.shape[0], weight.shape[1]
+        cop, cip = ceil32(co), ceil32(ci)
+        w = _chk(weight.detach(), "weight")
+        ent.wf = _new((4, cop, 3, cip), w)
+        ent.wb = _new((4, cip, 3, cop), w)
+        call("adm_pack_weight_wino", ptr(w), ptr(ent.wf), ptr(ent.wb), co, ci, cop, cip)
+        _pack_table = None           # the one-launch repack table must learn the new destinations
+    return ent.wf, ent.wb
+
+
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
 
 
@@ -106,6 +127,8 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     ent = _Packed()
     ent.key = key
     ent.fwd16 = ent.bwd16 = None
+    ent.wf = ent.wb = None
+    ent.src = (co, ci, ks, qkv)
     ent.fwd = _new((cop, ks * ks * cip), w)
     ent.bwd = _new((cip, ks * ks * cop), w)
     call("adm_pack_weight", ptr(w), ptr(ent.fwd), ptr(ent.bwd), co, ci, ks, cop, cip, int(qkv))
@@ -152,7 +175,8 @@ def repack_all():
                 continue
             co, ci = w.shape[0], w.shape[1]
             cop, cip = ceil32(co), ceil32(ci)
-            rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv), tiles])
+            rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv), tiles,
+                         0 if ent.wf is None else ent.wf.data_ptr(), 0 if ent.wb is None else ent.wb.data_ptr()])
             tiles += (cop // 32) * (cip // 32)         # column 9 = exclusive prefix sum of 32x32 tiles
             ents.append((wref, bref, ks, qkv, ent))
         if not rows:
@@ -234,8 +258,16 @@ def _queue_join_at_end_of_backward():
 # ------------------------------------------------------------------------------------------------
 # convolution / linear
 # ------------------------------------------------------------------------------------------------
-def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile):
-    """fp32 implicit GEMM; small-M problems get the deterministic split-K path (workspace + fixed-order reduce)."""
+def _use_wino(B, Ho, Wo, ks, up, tile) -> bool:
+    return WINOGRAD and ks == 3 and not up and tile < 0 and (Wo & 1) == 0 and B * Ho * Wo >= WINO_MIN_M
+
+
+def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None):
+    """fp32 conv: Winograd F(2,3) kernel when `wq` (its operand) is given, else the direct implicit GEMM; small-M problems
+    get the deterministic split-K path (workspace + fixed-order reduce)."""
+    if wq is not None:
+        call("adm_conv_fwd_wino", ptr(x), ptr(wq), ptr(bias), ptr(res), ptr(y), B, Ho, Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
+        return
     if tile < 0:
         sk = hip.lib().adm_conv_splitk(B * Ho * Wo, n_p, ks * ks * cin_p)
         if sk > 1:
@@ -270,7 +302,8 @@ class _Conv(torch.autograd.Function):
                 call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
                      Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
-                _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile)
+                wq = _wino_operands(weight, pk)[0] if (_use_wino(B, Ho, Wo, ks, up, tile) and not qkv) else None
+                _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq)
         ctx.save_for_backward(x, weight, bias)
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
         return y
@@ -358,7 +391,8 @@ class _Conv(torch.autograd.Function):
                     call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
                          cop, cop, cip, cip, cip, cip, ks, 0, -1)
                 else:
-                    _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1)
+                    wq = _wino_operands(weight, pk)[1] if (_use_wino(B, Ho, Wo, ks, False, -1) and not qkv) else None
+                    _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1, wq)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
                 call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)

@@ -49,6 +49,16 @@ int adm_conv_fwd_strided(const float* x, const float* wp, const float* bias, con
                          int B, int Hin, int Win, int Hout, int Wout, int Cin, int ldx, int N, int wrows,
                          int ldy, int ldr, int ks, int stride, int pad_lo, hipStream_t stream);
 
+/* 3x3 stride-1 conv (forward / data gradient) through a 1-D Winograd F(2,3) transform along x: 1.5x fewer MFMA flops than
+ * adm_conv_fwd, same NHWC contract (up = 0, ks = 3), W even, Cin % 16 == 0.  wq = adm_pack_weight_wino's operand
+ * [4][wrows][3][Cin] (G g applied at pack time: 1, (g0+g1+g2)/2, (g0-g1+g2)/2, 1).  fp32 throughout; not bit-identical to the
+ * direct kernel (different summation), same tolerance.  F.conv2d of Conv2d.forward, uncond_unet.py:98-110. */
+int adm_conv_fwd_wino(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H, int W,
+                      int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
+/* OIHW [Co][Ci][3][3] -> wf [4][Co_pad][3][Ci_pad] (forward) and wb [4][Ci_pad][3][Co_pad] (data gradient: taps flipped,
+ * channels transposed); either may be NULL. */
+int adm_pack_weight_wino(const float* w, float* wf, float* wb, int Co, int Ci, int Co_pad, int Ci_pad, hipStream_t stream);
+
 /* Deterministic split-K for the small-M layers (4x4 resolution, embedding Linears): adm_conv_splitk(M, N, K) is the
  * number of K slices the library would use (1 = none); adm_conv_fwd_ws is adm_conv_fwd with a workspace of at least
  * splitk*M*N floats: partial tiles are written there and summed (+ bias, + res) in a fixed order by a second launch. */
@@ -88,9 +98,10 @@ int adm_f32_to_bf16(const float* src, unsigned short* dst, long n, hipStream_t s
  * Either output may be NULL. */
 int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci, int ks, int Co_pad, int Ci_pad,
                     int qkv, hipStream_t stream);
-/* adm_pack_weight for every layer of a model in ONE launch (used after each optimiser step).  table = device array of
- * n_entries rows of 10 int64: {src, dst_fwd, dst_bwd, Co, Ci, ks*ks, Co_pad, Ci_pad, qkv, tile_begin}, tile_begin = the
- * exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) in row order; total_tiles = the sum.  Both outputs are required. */
+/* adm_pack_weight (+ adm_pack_weight_wino) for every layer of a model in ONE launch (used after each optimiser step).
+ * table = device array of n_entries rows of 12 int64: {src, dst_fwd, dst_bwd, Co, Ci, ks*ks, Co_pad, Ci_pad, qkv, tile_begin,
+ * dst_wino_fwd, dst_wino_bwd}; tile_begin = the exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) in row order; total_tiles =
+ * the sum; the Winograd destinations may be 0.  dst_fwd / dst_bwd are required. */
 int adm_pack_weight_table(const long* table, int n_entries, long total_tiles, hipStream_t stream);
 /* inverse of the fwd packing for gradients: dw OIHW = (accumulate ? dw : 0) + dwp */
 int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,

@@ -74,8 +74,14 @@ def test_precond_small_vs_golden(gpu, golden_dir, variant, use_aug):
             assert abs(gn - float(g[p + "gradnorm." + name])) <= 2e-3 * float(g[p + "gradnorm." + name]) + 1e-6, name
 
 
-def test_every_parameter_gets_the_oracle_gradient(gpu):
-    """All 400+ parameter gradients of the reduced two-decoder model vs autograd through the CPU oracle."""
+@pytest.mark.parametrize("winograd", [False, True])
+def test_every_parameter_gets_the_oracle_gradient(gpu, monkeypatch, winograd):
+    """All 400+ parameter gradients of the reduced two-decoder model vs autograd through the CPU oracle -- once with every
+    3x3 conv on the direct implicit GEMM and once with every eligible one forced through the Winograd F(2,3) kernel (at
+    this test's batch of 2 the size threshold would otherwise keep them all on the direct kernel)."""
+    from adm_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD", winograd)
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     m, cfg, sd = build_unet("uncond_unet", gpu)
     m.eval()
     x, sigma, aug = small_inputs(cfg)

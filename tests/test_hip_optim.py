@@ -123,7 +123,11 @@ def test_table_repack_equals_per_layer_pack():
     from adm_amd.hip import call, ptr
     gpu = torch.device("cuda:0")
     m = _model(gpu)
-    _loss(m, gpu).backward()                       # populates the packed-operand cache for every layer
+    old_min, ops.WINO_MIN_M = ops.WINO_MIN_M, 1    # batch 2: force the 3x3 layers through Winograd so their operands exist
+    try:
+        _loss(m, gpu).backward()                   # populates the packed-operand cache for every layer
+    finally:
+        ops.WINO_MIN_M = old_min
     ents = [(w(), ks, qkv) for w, _b, ks, qkv in ops._pack_registry.values() if w() is not None and w().is_cuda]
     mine = [(w, ks, qkv) for (w, ks, qkv) in ents if any(w is p for p in m.parameters())]
     assert len(mine) > 50
@@ -139,5 +143,10 @@ def test_table_repack_equals_per_layer_pack():
         f, b = torch.empty_like(ent.fwd), torch.empty_like(ent.bwd)
         call("adm_pack_weight", ptr(w.detach()), ptr(f), ptr(b), co, ci, ks, cop, cip, int(qkv))
         assert torch.equal(f, ent.fwd) and torch.equal(b, ent.bwd), (tuple(w.shape), ks, qkv)
+        if ent.wf is not None:                     # Winograd operands of the 3x3 layers ride in the same launch
+            wf, wb = torch.empty_like(ent.wf), torch.empty_like(ent.wb)
+            call("adm_pack_weight_wino", ptr(w.detach()), ptr(wf), ptr(wb), co, ci, cop, cip)
+            assert torch.equal(wf, ent.wf) and torch.equal(wb, ent.wb), tuple(w.shape)
+            kinds.add("wino")
         kinds.add((ks, bool(qkv), cop != co, cip != ci))
-    assert {(3, False, False, True), (3, False, True, False), (1, True, False, False), (1, False, False, False)} <= kinds
+    assert {(3, False, False, True), (3, False, True, False), (1, True, False, False), (1, False, False, False), "wino"} <= kinds
