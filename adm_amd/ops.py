@@ -297,12 +297,14 @@ class _Conv(torch.autograd.Function):
             if tuple(res.shape) != tuple(y.shape):
                 raise RuntimeError(f"residual shape {tuple(res.shape)} != output {tuple(y.shape)}")
         bf16 = COMPUTE == "bf16"
-        with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"fwd M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
-            if bf16 and cip % 64 == 0:
+        use_bf16 = bf16 and cip % 64 == 0
+        wq = _wino_operands(weight, pk)[0] if (not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv) else None
+        with _Prof("wino" if wq is not None else "igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks,
+                   f"fwd{'-wino' if wq is not None else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
+            if use_bf16:
                 call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
                      Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
-                wq = _wino_operands(weight, pk)[0] if (_use_wino(B, Ho, Wo, ks, up, tile) and not qkv) else None
                 _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq)
         ctx.save_for_backward(x, weight, bias)
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
@@ -386,12 +388,14 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             pk = packed(weight, bias, ks, qkv)
             dxf = _new((B, Ho, Wo, cip), dy)
-            with _Prof("igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks, f"dgrad M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
-                if bf16 and cop % 64 == 0:
+            use_bf16 = bf16 and cop % 64 == 0
+            wq = _wino_operands(weight, pk)[1] if (not use_bf16 and _use_wino(B, Ho, Wo, ks, False, -1) and not qkv) else None
+            with _Prof("wino" if wq is not None else "igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks,
+                       f"dgrad{'-wino' if wq is not None else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
+                if use_bf16:
                     call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
                          cop, cop, cip, cip, cip, cip, ks, 0, -1)
                 else:
-                    wq = _wino_operands(weight, pk)[1] if (_use_wino(B, Ho, Wo, ks, False, -1) and not qkv) else None
                     _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1, wq)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
