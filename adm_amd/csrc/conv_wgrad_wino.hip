@@ -1,0 +1,209 @@
+// Weight gradient of the 3x3 stride-1 convs through the TRANSPOSED 1-D Winograd form F(3,2) along x (fp32 MFMA).
+//
+//   dW[co][ky][kx][ci] = sum_{b,y,x} dY[b,y,x][co] * X[b, y+ky-1, x+kx-1][ci]
+// Per output-pixel pair (x0 = 2xp, x0+1) and filter row ky, with e = dY[x0], dY[x0+1] and d_i = X[.., x0-1+i] (i = 0..3), the
+// three taps are W_kx = e0 d_kx + e1 d_{kx+1}: 6 multiplies.  Transposing F(2,3) (conv_wino.hip) gives 4:
+//     a = A e   = (e0, e0+e1, e0-e1, -e1)            b = B^T d = (d0-d2, d1+d2, d2-d1, d1-d3)          (only +-1)
+//     m_xi = sum_pairs a_xi * b_xi                     (four GEMMs, reduction over pixel pairs)
+//     W_0 = m0 + (m1+m2)/2     W_1 = (m1-m2)/2     W_2 = (m1+m2)/2 + m3                                 (epilogue)
+// i.e. 1.5x fewer MFMA flops than conv_wgrad.hip; constants +-1 and 1/2 only (fp32 error at the direct kernel's level).
+//
+// Structure = conv_wgrad.hip's: both operands arrive pixel-major and are TRANSPOSED on their way into LDS (channel rows,
+// pair columns) after the 3 + 4 float4 add/sub of the transforms; grid = (Cout/64 x Cin/64 tiles, 3 filter rows, splits
+// of the pair range), fp32 atomics when split.  One workgroup = 64 couts x 64 cins x 4 xi (4 accumulator tiles per wave),
+// K-step 16 pairs, 64 KB LDS (rows of 16 floats, slots XOR-swizzled as in conv_wino.hip; the four quad groups of a wave
+// write DIFFERENT channel residues in each store round so that the transposing ds_write_b32 stays conflict-free).
+// The bias gradient rides along: sum(e0 + e1) is the xi = 1 component of A e.
+// Power-of-two H and W only (every DDM shape); anything else stays on conv_wgrad.hip.
+#include "common.h"
+#include "../../include/adm_hip.h"
+
+namespace {
+
+struct WwP {
+  const float* x; const float* dy; float* dwp; float* dbias;
+  int Pp, H, W, lw, lh, Cin, ldx, Cout, lddy, tilesN, chunk, atomic, xbytes, dybytes;   // Pp = pixel pairs, chunk in pairs
+};
+
+constexpr int WT = 64, WKK = 16;       // 64 x 64 channel tile, 16 pairs per stage
+
+__global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                               // [2][4][WT][WKK]   a_xi, rows = cout
+  float* Bs = smem + 2 * 4 * WT * WKK;            // [2][4][WT][WKK]   b_xi, rows = cin
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+  const int co0 = tm * WT, ci0 = tn * WT;
+  const int ky = blockIdx.y;
+  const int pbeg = blockIdx.z * p.chunk;
+  const int pend = min(p.Pp, pbeg + p.chunk);
+  if (pbeg >= pend) return;
+  const int KT = (pend - pbeg + WKK - 1) / WKK;
+
+  // loader: thread = (pair lk of the stage, channel quad): 16 pairs x 16 quads (64 channels) per operand
+  const int lk = lane & 15, lq = lane >> 4;
+  const int quad = wid * 4 + lq;                  // 0..15
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dybytes, 0x00020000);
+  // X is addressed relative to pixel (2p) + (ky-1) W - 1, the position of d0: fold that shift into the descriptor base
+  const int shift = ((ky - 1) * p.W - 1) * p.ldx;
+  const __amdgpu_buffer_rsrc_t rs_xt =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, max(0, p.xbytes - shift * 4), 0x00020000);
+  const unsigned a_col = (co0 + quad * 4 < p.Cout) ? (unsigned)(co0 + quad * 4) * 4u : OOB;
+  const unsigned b_col = (ci0 + quad * 4 < p.Cin) ? (unsigned)(ci0 + quad * 4) * 4u : OOB;
+  const unsigned a_voff = (a_col != OOB) ? (unsigned)(2 * lk * p.lddy) * 4u + a_col : OOB;     // e0; e1 is one pixel further
+  const unsigned b_voff = (b_col != OOB) ? (unsigned)(2 * lk * p.ldx) * 4u + b_col : OOB;      // d0; d_i is i pixels further
+  const int Wh = p.W >> 1;
+
+  f32x4 e[2], d[4];
+  auto load_stage = [&](int s) {
+    const int pb = pbeg + s * WKK;
+    const int pr = pb + lk;                                         // this thread's pair
+    const bool pv = pr < pend;
+    const int xp = pr & (Wh - 1), y = (pr >> (p.lw - 1)) & (p.H - 1);
+    const bool rv = pv && (unsigned)(y + ky - 1) < (unsigned)p.H;
+    const int a_soff = 2 * pb * p.lddy * 4, b_soff = 2 * pb * p.ldx * 4;
+    const unsigned av = pv ? a_voff : OOB;
+    e[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)av, a_soff, 0));
+    e[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(av + (pv ? p.lddy * 4 : 0)), a_soff, 0));
+    const unsigned bv = rv ? b_voff : OOB;
+    const unsigned step = (unsigned)p.ldx * 4u;
+    d[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)((rv && xp > 0) ? bv : OOB), b_soff, 0));
+    d[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(rv ? bv + step : OOB), b_soff, 0));
+    d[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(rv ? bv + 2 * step : OOB), b_soff, 0));
+    d[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)((rv && xp < Wh - 1) ? bv + 3 * step : OOB), b_soff, 0));
+  };
+  const bool do_bias = p.dbias != nullptr && tn == 0 && ky == 0;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  // transposing store: element (channel c = quad*4 + jj, pair lk) of plane xi -> row c, swizzled column
+  //   float offset = c*16 + (((lk >> 2) ^ ((c >> 2) & 3)) << 2) + (lk & 3),  (c >> 2) & 3 = quad & 3
+  const int colw = ((((lk >> 2) ^ (quad & 3)) << 2) + (lk & 3));
+  auto store_stage = [&](int buf) {
+    f32x4 a[4], b[4];
+    a[0] = e[0]; a[1] = e[0] + e[1]; a[2] = e[0] - e[1]; a[3] = -e[1];
+    b[0] = d[0] - d[2]; b[1] = d[1] + d[2]; b[2] = d[2] - d[1]; b[3] = d[1] - d[3];
+    if (do_bias) bsum += a[1];
+    float* la = As + buf * 4 * WT * WKK + quad * 4 * WKK + colw;
+    float* lb = Bs + buf * 4 * WT * WKK + quad * 4 * WKK + colw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jj = (j + lq) & 3;                // rotate the channel residue across the wave's four quad groups
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        la[xi * WT * WKK + jj * WKK] = a[xi][jj];
+        lb[xi * WT * WKK + jj * WKK] = b[xi][jj];
+      }
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+  int foff[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) foff[g] = lr * WKK + (((2 * g + lh) ^ ((lr >> 2) & 3)) << 2);
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < KT; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < KT) load_stage(s + 1);
+    const float* Ab = As + buf * 4 * WT * WKK + wm * 32 * WKK;
+    const float* Bb = Bs + buf * 4 * WT * WKK + wn * 32 * WKK;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        a[xi] = *reinterpret_cast<const f32x4*>(Ab + xi * WT * WKK + foff[g]);
+        b[xi] = *reinterpret_cast<const f32x4*>(Bb + xi * WT * WKK + foff[g]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[xi][k], b[xi][k], acc[xi], 0, 0, 0);
+    }
+    if (s + 1 < KT) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (do_bias) {       // lanes lk = 0..15 of a quad group hold different pairs of the same channel quad
+    f32x4 v = bsum;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], o, 64);
+    if (lk == 0 && a_col != OOB) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(&p.dbias[co0 + quad * 4 + j], v[j]);
+    }
+  }
+  // ---- epilogue: G^T m.  rows = cout, cols = cin
+  const int ci = ci0 + wn * 32 + lr;
+  if (ci >= p.Cin) return;
+  const int cb = co0 + wm * 32 + 4 * lh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = cb + (r & 3) + 8 * (r >> 2);
+    if (co >= p.Cout) continue;
+    const float h = 0.5f * (acc[1][r] + acc[2][r]);
+    const float w0 = acc[0][r] + h, w1 = 0.5f * (acc[1][r] - acc[2][r]), w2 = h + acc[3][r];
+    float* dst = p.dwp + ((long)co * 9 + ky * 3) * p.Cin + ci;
+    if (p.atomic) {
+      atomicAdd(dst, w0); atomicAdd(dst + p.Cin, w1); atomicAdd(dst + 2 * p.Cin, w2);
+    } else {
+      dst[0] = w0; dst[p.Cin] = w1; dst[2 * p.Cin] = w2;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
+                                   int ldx, int Cout, int lddy, int splits, hipStream_t stream) {
+  if (!x || !dy || !dwp || B <= 0 || H <= 0 || W < 2) return ADM_EINVAL;
+  if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)dy) & 15) return ADM_EINVAL;
+  auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  const int lw = ilog2(W), lh = ilog2(H);
+  if (lw < 1 || lh < 0) return ADM_EINVAL;                    // power-of-two H, W (W >= 2) only
+  WwP p;
+  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
+  const long P = (long)B * H * W;
+  const long xb = P * ldx * 4, db = P * lddy * 4;
+  if (xb >= (1L << 31) - (1L << 22) || db >= (1L << 31) - (1L << 22)) return ADM_EINVAL;   // 32-bit offsets, with room for the tap shift
+  p.Pp = (int)(P / 2); p.H = H; p.W = W; p.lw = lw; p.lh = lh; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
+  p.xbytes = (int)xb; p.dybytes = (int)db;
+  p.tilesN = adm_cdiv(Cin, WT);
+  const long tiles = (long)adm_cdiv(Cout, WT) * p.tilesN * 3;
+  if (splits <= 0) {       // fill the 512 resident slots (2 workgroups per CU) in whole rounds, >= 64 pairs per split
+    const long slots = 512;
+    const int maxs = (p.Pp + 63) / 64;
+    splits = tiles >= slots ? 1 : (int)(slots / tiles);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  int chunk = ((p.Pp + splits - 1) / splits + WKK - 1) / WKK * WKK;
+  splits = (p.Pp + chunk - 1) / chunk;
+  p.chunk = chunk;
+  p.atomic = splits > 1;
+  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 9 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
+  static bool attr_set = false;
+  constexpr int smem = 2 * 4 * (WT + WT) * WKK * (int)sizeof(float);
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess)
+      return ADM_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(adm_cdiv(Cout, WT) * p.tilesN, 3, splits);
+  hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(256), smem, stream, p);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}

@@ -79,6 +79,12 @@ int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, in
 int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx,
                         int Cout, int lddy, int ks, int up, int splits, hipStream_t stream);
 
+/* adm_conv_wgrad_bias for 3x3 stride-1 convs through the transposed Winograd form F(3,2) along x (1.5x fewer MFMA flops;
+ * fp32; power-of-two H and W >= 2).  Same outputs: dwp[Cout][9][Cin] (zero-filled by the call when it splits) and the
+ * optional dbias accumulation.  Autograd of F.conv2d's weight, uncond_unet.py:98-110. */
+int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx,
+                        int Cout, int lddy, int splits, hipStream_t stream);
+
 /* ---- reduced-precision option (BASELINE.json configs[2], "bf16"): same contracts as adm_conv_fwd / adm_conv_wgrad,
  * tensors stay fp32 in HBM, the contraction runs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 on their way
  * into LDS, fp32 accumulation).  wp16 = the adm_pack_weight layouts converted with adm_f32_to_bf16.  Cin % 64 == 0
