@@ -349,7 +349,7 @@ class _Conv(torch.autograd.Function):
                         dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
                 wino_w = (not bf16 and _use_wino(B, Ho, Wo, ks, up, -1) and not qkv and pow2(Ho) and pow2(Wo))
-                with _Prof("wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks,
+                with _Prof("wgrad_wino" if wino_w else "wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"wgrad{'-wino' if wino_w else ''} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16:
                         call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)

@@ -289,9 +289,16 @@ def main():
                                     "achieved": round(fl1 / ms1 / 1e9, 2), "frac": round(fl1 / ms1 / 1e9 / peak, 4),
                                     "launches_per_step": n1, "ms_per_step_in_kernel": round(ms1, 2),
                                     "mfma_busy_pmc": pmc_all.get("igemm", {}).get("mfma_busy_fraction")}
+        if "wgrad_wino" in by:
+            fl4, ms4, n4 = by["wgrad_wino"]
+            roof["wgrad_wino"] = {"kernel": "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3,2))",
+                                  "achieved": round(fl4 / ms4 / 1e9, 2), "frac": round(fl4 / ms4 / 1e9 / peak, 4),
+                                  "executed": round(fl4 * 2 / 3 / ms4 / 1e9, 2), "frac_executed": round(fl4 * 2 / 3 / ms4 / 1e9 / peak, 4),
+                                  "launches_per_step": n4, "ms_per_step_in_kernel": round(ms4, 2),
+                                  "mfma_busy_pmc": pmc_all.get("wgrad_wino", {}).get("mfma_busy_fraction")}
         if "wgrad" in by:
             fl2, ms2, n2 = by["wgrad"]
-            roof["wgrad"] = {"kernel": "wgrad_f32_kernel", "achieved": round(fl2 / ms2 / 1e9, 2),
+            roof["wgrad"] = {"kernel": "wgrad_f32_kernel (direct: 1x1 / Linear / small-map / fused-upsample layers)", "achieved": round(fl2 / ms2 / 1e9, 2),
                              "frac": round(fl2 / ms2 / 1e9 / peak, 4), "launches_per_step": n2,
                              "ms_per_step_in_kernel": round(ms2, 2),
                              "mfma_busy_pmc": pmc_all.get("wgrad", {}).get("mfma_busy_fraction")}

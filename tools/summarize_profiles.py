@@ -15,7 +15,7 @@ def load(pattern):
 
 
 def cls(n):
-    return ("wgrad" if "wgrad" in n else "wino" if "wino" in n else "igemm" if "igemm" in n else "attn" if "attn" in n else "gn" if "::gn_" in n
+    return ("wgrad_wino" if "wgrad_wino" in n else "wgrad" if "wgrad" in n else "wino" if "wino" in n else "igemm" if "igemm" in n else "attn" if "attn" in n else "gn" if "::gn_" in n
             else "other")
 
 
