@@ -15,6 +15,7 @@
 // write DIFFERENT channel residues in each store round so that the transposing ds_write_b32 stays conflict-free).
 // The bias gradient rides along: sum(e0 + e1) is the xi = 1 component of A e.
 // Power-of-two H and W only (every DDM shape); anything else stays on conv_wgrad.hip.
+#include <algorithm>
 #include "common.h"
 #include "../../include/adm_hip.h"
 
@@ -182,12 +183,20 @@ extern "C" int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, 
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, WT);
   const long tiles = (long)adm_cdiv(Cout, WT) * p.tilesN * 3;
-  if (splits <= 0) {       // fill the 512 resident slots (2 workgroups per CU) in whole rounds, >= 64 pairs per split
+  if (splits <= 0) {
+    // 512 resident slots (2 workgroups per CU).  Pick the split count whose workgroup total fills whole rounds best
+    // (tiles * s close below a multiple of 512), with a mild preference for fewer splits (atomics, shorter K loops);
+    // >= 64 pairs per split.  E.g. 384 x 384: 108 tiles -> s = 4 fills 84 % of one round, s = 14 fills 98 % of three.
     const long slots = 512;
-    const int maxs = (p.Pp + 63) / 64;
-    splits = tiles >= slots ? 1 : (int)(slots / tiles);
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
+    const int maxs = (int)std::min<long>((p.Pp + 63) / 64, 32);
+    double best = -1.0;
+    splits = 1;
+    for (int sN = 1; sN <= maxs; ++sN) {
+      const long wgs = tiles * sN;
+      const long rounds = (wgs + slots - 1) / slots;
+      const double fill = (double)wgs / (double)(rounds * slots) - 0.002 * sN;
+      if (fill > best + 1e-9) { best = fill; splits = sN; }
+    }
   }
   int chunk = ((p.Pp + splits - 1) / splits + WKK - 1) / WKK * WKK;
   splits = (p.Pp + chunk - 1) / chunk;
