@@ -108,3 +108,26 @@ def test_sampler_step_fixed_point_and_range(ops):
     assert torch.equal(y, x)
     z = ops.sampler_step((x * 3).clone(), zero, zero, 1e-4, 0.0, 0, True, 1.0, True)
     assert float(z.min()) >= 0.0 and float(z.max()) <= 1.0
+
+
+@pytest.mark.parametrize("B,H,cin,cout", [(128, 32, 192, 192), (128, 16, 768, 384), (128, 8, 384, 384)])
+def test_winograd_and_direct_kernels_agree_full_size(ops, monkeypatch, B, H, cin, cout):
+    """At BASELINE's sizes the 3x3 convs run through the Winograd F(2,3) / F(3,2) kernels; forward, data gradient, weight
+    gradient and bias gradient must agree with the direct implicit-GEMM kernels to fp32 rounding (different summation
+    orders, same arithmetic)."""
+    x = rnd((B, H, H, cin), 11)
+    w0 = rnd((cout, cin, 3, 3), 12, 1 / math.sqrt(cin * 9))
+    b0 = rnd((cout,), 13)
+    gy = rnd((B, H, H, cout), 14)
+    out = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", mode)
+        xd = x.clone().requires_grad_(True)
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = ops.conv2d(xd, w, b)
+        assert (w._adm_packed.wf is not None) == mode
+        (y * gy).sum().backward()
+        out[mode] = (y.detach(), xd.grad, w.grad, b.grad)
+    for got, want, name in zip(out[True], out[False], ("y", "dx", "dw", "db")):
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err <= 2e-5, (name, err)
