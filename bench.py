@@ -302,6 +302,14 @@ def main():
                              "frac": round(fl2 / ms2 / 1e9 / peak, 4), "launches_per_step": n2,
                              "ms_per_step_in_kernel": round(ms2, 2),
                              "mfma_busy_pmc": pmc_all.get("wgrad", {}).get("mfma_busy_fraction")}
+        if "gn" in by:      # the HBM-bound part of the ResBlock: GroupNorm + scale/shift + SiLU + dropout, forward and backward
+            by3, ms5, n5 = by["gn"]                 # `flops` slot carries algorithmic bytes (12 B/elem fwd, 20 B/elem bwd)
+            roof["groupnorm"] = {"kernel": "gn_* (GroupNorm+SiLU+dropout fwd/bwd)", "bound": "hbm",
+                                 "achieved": round(by3 / ms5 / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(by3 / ms5 / 1e6 / 8000.0, 4), "calls_per_step": n5,
+                                 "ms_per_step_in_kernel": round(ms5, 2),
+                                 "note": "algorithmic bytes of the multi-pass formulation (x read twice + y written; x, dy read "
+                                         "twice + dx written); the register-resident small-map kernels move fewer"}
         if "attn" in by:
             fl3, ms3, n3 = by["attn"]
             roof["attention"] = {"kernel": "attn_fwd/bwd kernels", "achieved": round(fl3 / ms3 / 1e9, 2),
