@@ -28,6 +28,7 @@ struct WwP {
 
 constexpr int WT = 64, WKK = 16;       // 64 x 64 channel tile, 16 pairs per stage
 
+template <bool UP>
 __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                               // [2][4][WT][WKK]   a_xi, rows = cout
@@ -69,8 +70,22 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
     const unsigned av = pv ? a_voff : OOB;
     e[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)av, a_soff, 0));
     e[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(av + (pv ? p.lddy * 4 : 0)), a_soff, 0));
-    const unsigned bv = rv ? b_voff : OOB;
     const unsigned step = (unsigned)p.ldx * 4u;
+    if (UP) {
+      // fused nearest x2 (Conv2d(up=True)): X is [B][H/2][W/2]; up-sampled row y+ky-1 reads input row (y+ky-1)>>1 and the
+      // columns 2xp-1..2xp+2 read xp-1, xp, xp, xp+1
+      const int bimg = pr >> (p.lw - 1 + p.lh);
+      const int irow = (y + ky - 1) >> 1;
+      const unsigned base = (rv && b_col != OOB)
+          ? (unsigned)((((long)bimg * (p.H >> 1) + irow) * Wh + xp) * p.ldx) * 4u + b_col : OOB;
+      const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
+      d[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((base != OOB && xp > 0) ? base - step : OOB), 0, 0));
+      d[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)base, 0, 0));
+      d[2] = d[1];
+      d[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((base != OOB && xp < Wh - 1) ? base + step : OOB), 0, 0));
+      return;
+    }
+    const unsigned bv = rv ? b_voff : OOB;
     d[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)((rv && xp > 0) ? bv : OOB), b_soff, 0));
     d[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(rv ? bv + step : OOB), b_soff, 0));
     d[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(rv ? bv + 2 * step : OOB), b_soff, 0));
@@ -166,9 +181,11 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
 
 }  // namespace
 
-extern "C" int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
-                                   int ldx, int Cout, int lddy, int splits, hipStream_t stream) {
+namespace {
+int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
+                    int lddy, int splits, int up, hipStream_t stream) {
   if (!x || !dy || !dwp || B <= 0 || H <= 0 || W < 2) return ADM_EINVAL;
+  if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
   if (((uintptr_t)x | (uintptr_t)dy) & 15) return ADM_EINVAL;
   auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
@@ -177,7 +194,7 @@ extern "C" int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, 
   WwP p;
   p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
   const long P = (long)B * H * W;
-  const long xb = P * ldx * 4, db = P * lddy * 4;
+  const long xb = (up ? P / 4 : P) * ldx * 4, db = P * lddy * 4;
   if (xb >= (1L << 31) - (1L << 22) || db >= (1L << 31) - (1L << 22)) return ADM_EINVAL;   // 32-bit offsets, with room for the tap shift
   p.Pp = (int)(P / 2); p.H = H; p.W = W; p.lw = lw; p.lh = lh; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
   p.xbytes = (int)xb; p.dybytes = (int)db;
@@ -203,16 +220,31 @@ extern "C" int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, 
   p.chunk = chunk;
   p.atomic = splits > 1;
   if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 9 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
-  static bool attr_set = false;
   constexpr int smem = 2 * 4 * (WT + WT) * WKK * (int)sizeof(float);
+  static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   dim3 grid(adm_cdiv(Cout, WT) * p.tilesN, 3, splits);
-  hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(256), smem, stream, p);
+  if (up) hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(256), smem, stream, p);
+  else hipLaunchKernelGGL(wgrad_wino_kernel<false>, grid, dim3(256), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
+}
+}  // namespace
+
+extern "C" int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
+                                   int ldx, int Cout, int lddy, int splits, hipStream_t stream) {
+  return wgrad_wino_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, 0, stream);
+}
+
+// Weight gradient of Conv2d(up=True): x is the conv's HALF-resolution input [B][H/2][W/2][ldx]; H x W is dy's grid.
+extern "C" int adm_conv_wgrad_wino_up(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
+                                      int ldx, int Cout, int lddy, int splits, hipStream_t stream) {
+  return wgrad_wino_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, 1, stream);
 }

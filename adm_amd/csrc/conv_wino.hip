@@ -34,6 +34,7 @@ struct WinoP {
 typedef __attribute__((address_space(3))) void wino_lds_void;
 constexpr int WP = 64, WN_ = 64, WK = 16;         // pairs x couts x K-step
 
+template <bool UP>
 __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                               // [2][4][WP][WK]
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
   unsigned a_base = 0;            // byte offset of pixel (b, y, 2xp), channel quad aq
   unsigned colmask = 0;           // bit i: d_i's column 2xp-1+i is inside the image
   unsigned rowmask = 0;           // bit ky: row y+ky-1 is inside the image
+  int ypar = 0;                   // UP: parity of y (selects the input row of each filter row)
   {
     const int pr = mp0 + pl;
     if (pr < p.Mp) {
@@ -66,7 +68,13 @@ __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
       const int t = pr / p.Wh;
       const int y = t % p.H;
       const int x0 = 2 * xp;
-      a_base = (unsigned)(((long)t * p.W + x0) * p.ldx + aq * 4) * 4u;       // t = b*H + y
+      if (UP) {   // fused nearest x2: (y, x0) are coordinates of the up-sampled grid; the input is [B][H/2][W/2]
+        const int b = t / p.H;
+        a_base = (unsigned)((((long)b * (p.H >> 1) + (y >> 1)) * p.Wh + xp) * p.ldx + aq * 4) * 4u;
+        ypar = y & 1;
+      } else {
+        a_base = (unsigned)(((long)t * p.W + x0) * p.ldx + aq * 4) * 4u;     // t = b*H + y
+      }
       colmask = (x0 > 0 ? 1u : 0u) | 6u | (x0 + 2 < p.W ? 8u : 0u);
       rowmask = (y > 0 ? 1u : 0u) | 2u | (y + 1 < p.H ? 4u : 0u);
     }
@@ -91,10 +99,22 @@ __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
   auto issue_stage = [&](int buf) {               // global -> registers (A), global -> LDS (B) for the NEXT stage
     if (ld_cc == 0) {
       const bool rv = (rowmask >> ld_ky) & 1u;
-      const int rowoff = (ld_ky - 1) * p.W * p.ldx * 4;
+      if (UP) {
+        // input row of up-sampled row y+ky-1 is (y>>1) + floor((ypar + ky - 1) / 2); columns 2xp-1..2xp+2 map to
+        // xp-1, xp, xp, xp+1 (d1 == d2: the xi = 2 component B^T d vanishes identically)
+        const int dr = ((ypar + ld_ky + 1) >> 1) - 1;
+        const int rowoff = dr * p.Wh * p.ldx * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        a_voff[i] = (rv && ((colmask >> i) & 1u)) ? a_base + (unsigned)(rowoff + (i - 1) * p.ldx * 4) : OOB;
+        for (int i = 0; i < 4; ++i) {
+          const int dc = (i == 0) ? -1 : (i == 3) ? 1 : 0;
+          a_voff[i] = (rv && ((colmask >> i) & 1u)) ? a_base + (unsigned)(rowoff + dc * p.ldx * 4) : OOB;
+        }
+      } else {
+        const int rowoff = (ld_ky - 1) * p.W * p.ldx * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          a_voff[i] = (rv && ((colmask >> i) & 1u)) ? a_base + (unsigned)(rowoff + (i - 1) * p.ldx * 4) : OOB;
+      }
     }
     const int soff = ld_cc << 6;                  // 16 floats = 64 bytes per chunk
 #pragma unroll
@@ -216,29 +236,47 @@ extern "C" int adm_pack_weight_wino(const float* w, float* wf, float* wb, int Co
   return ADM_OK;
 }
 
-extern "C" int adm_conv_fwd_wino(const float* x, const float* wq, const float* bias, const float* res, float* y, int B,
-                                 int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream) {
+namespace {
+int conv_wino_impl(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H, int W,
+                   int Cin, int ldx, int N, int wrows, int ldy, int ldr, int up, hipStream_t stream) {
   if (!x || !wq || !y || B <= 0 || H <= 0 || W < 2 || (W & 1)) return ADM_EINVAL;
+  if (up && (H & 1)) return ADM_EINVAL;
   if ((Cin & 15) || (ldx & 3) || N <= 0 || wrows < N) return ADM_EINVAL;
   if (((uintptr_t)x | (uintptr_t)wq) & 15) return ADM_EINVAL;
   WinoP p;
   p.x = x; p.w = wq; p.bias = bias; p.res = res; p.y = y;
   const long Mp = (long)B * H * (W / 2);
-  const long xb = (long)B * H * W * ldx * 4, wb = 4L * wrows * 3 * Cin * 4;
+  const long xb = (up ? (long)B * (H / 2) * (W / 2) : (long)B * H * W) * ldx * 4, wb = 4L * wrows * 3 * Cin * 4;
   if (Mp >= (1L << 30) || xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;
   p.Mp = (int)Mp; p.N = N; p.H = H; p.W = W; p.Wh = W / 2; p.Cin = Cin; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * 3 * Cin;
   p.tilesN = adm_cdiv(N, WN_);
-  static bool attr_set = false;
   constexpr int smem = 2 * 4 * (WP + WN_) * WK * (int)sizeof(float);
+  static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   const long grid = (long)adm_cdiv(Mp, WP) * p.tilesN;
-  hipLaunchKernelGGL(igemm_wino_kernel, dim3((unsigned)grid), dim3(256), smem, stream, p);
+  if (up) hipLaunchKernelGGL(igemm_wino_kernel<true>, dim3((unsigned)grid), dim3(256), smem, stream, p);
+  else hipLaunchKernelGGL(igemm_wino_kernel<false>, dim3((unsigned)grid), dim3(256), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
+}
+}  // namespace
+
+extern "C" int adm_conv_fwd_wino(const float* x, const float* wq, const float* bias, const float* res, float* y, int B,
+                                 int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream) {
+  return conv_wino_impl(x, wq, bias, res, y, B, H, W, Cin, ldx, N, wrows, ldy, ldr, 0, stream);
+}
+
+// Same with the reference's `up` resampling fused: x is [B][H/2][W/2][ldx], nearest-x2 up-sampled on the fly to the H x W
+// grid the conv runs on (Conv2d.forward with up=True, uncond_unet.py:98-104; H, W = OUTPUT size, both even).
+extern "C" int adm_conv_fwd_wino_up(const float* x, const float* wq, const float* bias, const float* res, float* y, int B,
+                                    int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream) {
+  return conv_wino_impl(x, wq, bias, res, y, B, H, W, Cin, ldx, N, wrows, ldy, ldr, 1, stream);
 }

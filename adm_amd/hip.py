@@ -24,9 +24,11 @@ _SIGS = {
     "adm_conv_fwd_ws": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_strided": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_wino": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_fwd_wino_up": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "adm_pack_weight_wino": [P, P, P, I, I, I, I, P],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_wino_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bias": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],

@@ -259,14 +259,16 @@ def _queue_join_at_end_of_backward():
 # convolution / linear
 # ------------------------------------------------------------------------------------------------
 def _use_wino(B, Ho, Wo, ks, up, tile) -> bool:
-    return WINOGRAD and ks == 3 and not up and tile < 0 and (Wo & 1) == 0 and B * Ho * Wo >= WINO_MIN_M
+    """(Ho, Wo) = the grid the conv runs on; with `up` (fused nearest x2) both are even by construction."""
+    return WINOGRAD and ks == 3 and tile < 0 and (Wo & 1) == 0 and B * Ho * Wo >= WINO_MIN_M
 
 
 def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None):
     """fp32 conv: Winograd F(2,3) kernel when `wq` (its operand) is given, else the direct implicit GEMM; small-M problems
     get the deterministic split-K path (workspace + fixed-order reduce)."""
     if wq is not None:
-        call("adm_conv_fwd_wino", ptr(x), ptr(wq), ptr(bias), ptr(res), ptr(y), B, Ho, Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
+        call("adm_conv_fwd_wino_up" if up else "adm_conv_fwd_wino", ptr(x), ptr(wq), ptr(bias), ptr(res), ptr(y), B, Ho, Wo,
+             cin_p, cin_p, n_p, n_p, n_p, n_p)
         return
     if tile < 0:
         sk = hip.lib().adm_conv_splitk(B * Ho * Wo, n_p, ks * ks * cin_p)
@@ -354,7 +356,8 @@ class _Conv(torch.autograd.Function):
                     if bf16:
                         call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
                     elif wino_w:
-                        call("adm_conv_wgrad_wino", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, 0)
+                        call("adm_conv_wgrad_wino_up" if up else "adm_conv_wgrad_wino", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B,
+                             Ho, Wo, cip, cip, cop, cop, 0)
                     else:
                         call("adm_conv_wgrad_bias", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, ks,
                              int(up), 0)

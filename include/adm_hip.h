@@ -55,6 +55,10 @@ int adm_conv_fwd_strided(const float* x, const float* wp, const float* bias, con
  * direct kernel (different summation), same tolerance.  F.conv2d of Conv2d.forward, uncond_unet.py:98-110. */
 int adm_conv_fwd_wino(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H, int W,
                       int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
+/* adm_conv_fwd_wino with the nearest-x2 up-sampling of Conv2d(up=True) fused into the loader: x is [B][H/2][W/2][ldx],
+ * H x W is the OUTPUT grid (both even).  uncond_unet.py:98-104. */
+int adm_conv_fwd_wino_up(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H, int W,
+                         int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
 /* OIHW [Co][Ci][3][3] -> wf [4][Co_pad][3][Ci_pad] (forward) and wb [4][Ci_pad][3][Co_pad] (data gradient: taps flipped,
  * channels transposed); either may be NULL. */
 int adm_pack_weight_wino(const float* w, float* wf, float* wb, int Co, int Ci, int Co_pad, int Ci_pad, hipStream_t stream);
@@ -84,6 +88,10 @@ int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, float* dbia
  * optional dbias accumulation.  Autograd of F.conv2d's weight, uncond_unet.py:98-110. */
 int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx,
                         int Cout, int lddy, int splits, hipStream_t stream);
+
+/* adm_conv_wgrad_wino for Conv2d(up=True): x is the HALF-resolution input [B][H/2][W/2][ldx], H x W is dy's grid. */
+int adm_conv_wgrad_wino_up(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx,
+                           int Cout, int lddy, int splits, hipStream_t stream);
 
 /* ---- reduced-precision option (BASELINE.json configs[2], "bf16"): same contracts as adm_conv_fwd / adm_conv_wgrad,
  * tensors stay fp32 in HBM, the contraction runs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 on their way

@@ -84,9 +84,11 @@ def test_conv_forward_backward(ops, cin, cout, H, ks, up, tile):
     close(nchw(rd.grad)[:, :cout], rr.grad)
 
 
-@pytest.mark.parametrize("B,cin,cout,H,W", [(3, 32, 32, 8, 8), (2, 64, 96, 5, 6), (1, 3, 64, 16, 16), (2, 96, 3, 4, 32),
-                                            (4, 192, 192, 16, 16), (1, 32, 32, 1, 2)])
-def test_conv_winograd_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
+@pytest.mark.parametrize("B,cin,cout,H,W,up", [(3, 32, 32, 8, 8, False), (2, 64, 96, 5, 6, False), (1, 3, 64, 16, 16, False),
+                                               (2, 96, 3, 4, 32, False), (4, 192, 192, 16, 16, False), (1, 32, 32, 1, 2, False),
+                                               (2, 64, 32, 4, 4, True), (3, 32, 96, 8, 4, True), (1, 96, 64, 3, 5, True),
+                                               (2, 384, 384, 8, 8, True)])
+def test_conv_winograd_forward_backward(ops, monkeypatch, B, cin, cout, H, W, up):
     """The F(2,3) Winograd kernel (normally chosen for M >= 8192) on small shapes: odd heights, channel padding on both
     sides, width 2, bias + residual; forward and the data gradient go through it, the weight gradient is the shared
     kernel.  Also checked against the direct kernel, which must agree to rounding."""
@@ -95,16 +97,18 @@ def test_conv_winograd_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
     x = fill.hash_tensor((B, cin, H, W), f"wx{cin}{cout}", 1.0)
     w = fill.hash_tensor((cout, cin, 3, 3), f"ww{cin}{cout}", 1.0 / math.sqrt(cin * 9))
     b = fill.hash_tensor((cout,), f"wb{cin}{cout}", 0.5)
-    r = fill.hash_tensor((B, cout, H, W), f"wr{cin}{cout}", 1.0)
-    gy = fill.hash_tensor((B, cout, H, W), f"wg{cin}{cout}", 1.0)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)          # up: the reference's fused nearest x2 (Conv2d(up=True))
+    r = fill.hash_tensor((B, cout, Ho, Wo), f"wr{cin}{cout}", 1.0)
+    gy = fill.hash_tensor((B, cout, Ho, Wo), f"wg{cin}{cout}", 1.0)
     xr, wr, br, rr = [t.clone().requires_grad_(True) for t in (x, w, b, r)]
-    y_ref = F.conv2d(xr, wr, br, padding=1) + rr
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    y_ref = F.conv2d(xin, wr, br, padding=1) + rr
     (y_ref * gy).sum().backward()
     cip, cop = ops.ceil32(cin), ops.ceil32(cout)
     xd = nhwc(pad_c(x, cip)).requires_grad_(True)
     wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     rd = nhwc(pad_c(r, cop)).requires_grad_(True)
-    y = ops.conv2d(xd, wd, bd, rd)
+    y = ops.conv2d(xd, wd, bd, rd, up=up)
     assert wd._adm_packed.wf is not None, "the Winograd path was not taken"
     close(nchw(y)[:, :cout], y_ref)
     if cop > cout:
@@ -115,7 +119,7 @@ def test_conv_winograd_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
     close(bd.grad, br.grad)
     monkeypatch.setattr(ops, "WINOGRAD", False)
     with torch.no_grad():
-        yd = ops.conv2d(xd.detach(), dev(w), dev(b), rd.detach())
+        yd = ops.conv2d(xd.detach(), dev(w), dev(b), rd.detach(), up=up)
     assert float((y.detach() - yd).abs().max()) <= 1e-5 * float(yd.abs().max())
 
 
