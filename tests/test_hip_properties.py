@@ -131,3 +131,36 @@ def test_winograd_and_direct_kernels_agree_full_size(ops, monkeypatch, B, H, cin
     for got, want, name in zip(out[True], out[False], ("y", "dx", "dw", "db")):
         err = float((got - want).abs().max() / want.abs().max())
         assert err <= 2e-5, (name, err)
+
+
+def test_full_model_training_step_winograd_vs_direct(ops, monkeypatch):
+    """One loss + backward of the full 216 M-parameter model at bs=32 with the Winograd kernels on and off: the loss and
+    the global gradient norm must agree to fp32 rounding, and the largest per-parameter gradient deviation stays small
+    relative to that parameter's gradient norm."""
+    from adm_amd.ddm.ddm_const import DDPM
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    torch.manual_seed(0)
+    unet = EDMPrecond(img_resolution=32, img_channels=3, model_channels=192, channel_mult=[1, 2, 2, 2], channel_mult_emb=4,
+                      num_blocks=3, attn_resolutions=[16, 8], dropout=0.0, augment_dim=9)
+    with torch.no_grad():
+        for n, p in unet.named_parameters():
+            if float(p.abs().max()) == 0:
+                p.copy_(torch.empty_like(p).uniform_(-0.02, 0.02))
+    dpm = DDPM(model=unet, image_size=[32, 32], sampling_timesteps=10, perceptual_weight=0.0,
+               cfg=dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True)).cuda().train()
+    x0, noise = rnd((32, 3, 32, 32), 21), rnd((32, 3, 32, 32), 22, 1.7)
+    t = rnd((32,), 23, 0.45) + 0.5
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", mode)
+        dpm.zero_grad(set_to_none=True)
+        loss, _ = dpm.training_step({"image": x0}, t=t, noise=noise)
+        loss.backward()
+        res[mode] = (float(loss.detach()), {n: p.grad.clone() for n, p in dpm.named_parameters() if p.grad is not None})
+    (lw, gw), (ld, gd) = res[True], res[False]
+    assert abs(lw - ld) <= 1e-5 * abs(ld)
+    nw = math.sqrt(sum(float(g.double().pow(2).sum()) for g in gw.values()))
+    nd = math.sqrt(sum(float(g.double().pow(2).sum()) for g in gd.values()))
+    assert abs(nw - nd) <= 1e-4 * nd
+    worst = max(float((gw[n] - gd[n]).norm() / (gd[n].norm() + 1e-6 * nd)) for n in gd)
+    assert worst <= 2e-3, worst
