@@ -31,8 +31,8 @@ constexpr int WT = 64, WKK = 16;       // 64 x 64 channel tile, 16 pairs per sta
 template <bool UP>
 __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                               // [2][4][WT][WKK]   a_xi, rows = cout
-  float* Bs = smem + 2 * 4 * WT * WKK;            // [2][4][WT][WKK]   b_xi, rows = cin
+  float* As = smem;                               // [4][WT][WKK]   a_xi, rows = cout  (single-buffered: see the loop)
+  float* Bs = smem + 4 * WT * WKK;                // [4][WT][WKK]   b_xi, rows = cin
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
     a[0] = e[0]; a[1] = e[0] + e[1]; a[2] = e[0] - e[1]; a[3] = -e[1];
     b[0] = d[0] - d[2]; b[1] = d[1] + d[2]; b[2] = d[2] - d[1]; b[3] = d[1] - d[3];
     if (do_bias) bsum += a[1];
-    float* la = As + buf * 4 * WT * WKK + quad * 4 * WKK + colw;
-    float* lb = Bs + buf * 4 * WT * WKK + quad * 4 * WKK + colw;
+    float* la = As + quad * 4 * WKK + colw;
+    float* lb = Bs + quad * 4 * WKK + colw;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int jj = (j + lq) & 3;                // rotate the channel residue across the wave's four quad groups
@@ -127,10 +127,9 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
   store_stage(0);
   __syncthreads();
   for (int s = 0; s < KT; ++s) {
-    const int buf = s & 1;
     if (s + 1 < KT) load_stage(s + 1);
-    const float* Ab = As + buf * 4 * WT * WKK + wm * 32 * WKK;
-    const float* Bb = Bs + buf * 4 * WT * WKK + wn * 32 * WKK;
+    const float* Ab = As + wm * 32 * WKK;
+    const float* Bb = Bs + wn * 32 * WKK;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       f32x4 a[4], b[4];
@@ -145,7 +144,10 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
         for (int xi = 0; xi < 4; ++xi)
           acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[xi][k], b[xi][k], acc[xi], 0, 0, 0);
     }
-    if (s + 1 < KT) store_stage(buf ^ 1);
+    // both operands are register-staged, so LDS is single-buffered (32 KB per workgroup -> three workgroups per CU, the
+    // register limit, instead of two): one barrier after this stage's reads, one after the next stage's stores
+    __syncthreads();
+    if (s + 1 < KT) store_stage(0);
     __syncthreads();
   }
 
@@ -201,10 +203,10 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
   p.tilesN = adm_cdiv(Cin, WT);
   const long tiles = (long)adm_cdiv(Cout, WT) * p.tilesN * 3;
   if (splits <= 0) {
-    // 512 resident slots (2 workgroups per CU).  Pick the split count whose workgroup total fills whole rounds best
-    // (tiles * s close below a multiple of 512), with a mild preference for fewer splits (atomics, shorter K loops);
+    // 768 resident slots (3 workgroups per CU).  Pick the split count whose workgroup total fills whole rounds best
+    // (tiles * s close below a multiple of 768), with a mild preference for fewer splits (atomics, shorter K loops);
     // >= 64 pairs per split.  E.g. 384 x 384: 108 tiles -> s = 4 fills 84 % of one round, s = 14 fills 98 % of three.
-    const long slots = 512;
+    const long slots = 768;                      // 3 workgroups per CU (32 KB of LDS, 151 registers)
     const int maxs = (int)std::min<long>((p.Pp + 63) / 64, 32);
     double best = -1.0;
     splits = 1;
@@ -220,7 +222,7 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
   p.chunk = chunk;
   p.atomic = splits > 1;
   if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 9 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
-  constexpr int smem = 2 * 4 * (WT + WT) * WKK * (int)sizeof(float);
+  constexpr int smem = 4 * (WT + WT) * WKK * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,

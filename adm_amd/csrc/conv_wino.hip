@@ -37,8 +37,8 @@ constexpr int WP = 64, WN_ = 64, WK = 16;         // pairs x couts x K-step
 template <bool UP>
 __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                               // [2][4][WP][WK]
-  float* Bs = smem + 2 * 4 * WP * WK;             // [2][4][WN_][WK]
+  float* As = smem;                               // [4][WP][WK]  (single buffer: see the loop)
+  float* Bs = smem + 4 * WP * WK;                 // [2][4][WN_][WK]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
     if (++ld_cc == chunks) { ld_cc = 0; ++ld_ky; }
   };
   auto store_stage = [&](int buf) {               // B^T d, into the four xi planes
-    float* la = As + buf * 4 * WP * WK + pl * WK + a_slot;
+    float* la = As + pl * WK + a_slot;
     *reinterpret_cast<f32x4*>(la + 0 * WP * WK) = d[0] - d[2];
     *reinterpret_cast<f32x4*>(la + 1 * WP * WK) = d[1] + d[2];
     *reinterpret_cast<f32x4*>(la + 2 * WP * WK) = d[2] - d[1];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
   for (int s = 0; s < KT; ++s) {
     const int buf = s & 1;
     if (s + 1 < KT) issue_stage(buf ^ 1);
-    const float* Ab = As + buf * 4 * WP * WK + wm * 32 * WK;
+    const float* Ab = As + wm * 32 * WK;
     const float* Bb = Bs + buf * 4 * WN_ * WK + wn * 32 * WK;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -168,6 +168,9 @@ __global__ __launch_bounds__(256) void igemm_wino_kernel(WinoP p) {
         for (int xi = 0; xi < 4; ++xi)
           acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[xi][k], b[xi][k], acc[xi], 0, 0, 0);
     }
+    // A is single-buffered (48 KB of LDS per workgroup -> THREE workgroups per CU instead of two): one barrier after the
+    // reads of this stage, one after the next stage's stores (which also covers the B operand's DMA)
+    __syncthreads();
     if (s + 1 < KT) store_stage(buf ^ 1);
     __syncthreads();
   }
@@ -251,7 +254,7 @@ int conv_wino_impl(const float* x, const float* wq, const float* bias, const flo
   p.Mp = (int)Mp; p.N = N; p.H = H; p.W = W; p.Wh = W / 2; p.Cin = Cin; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * 3 * Cin;
   p.tilesN = adm_cdiv(N, WN_);
-  constexpr int smem = 2 * 4 * (WP + WN_) * WK * (int)sizeof(float);
+  constexpr int smem = (4 * WP + 2 * 4 * WN_) * WK * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
