@@ -11,7 +11,8 @@
 // Structure = conv_wgrad.hip's: both operands arrive pixel-major and are TRANSPOSED on their way into LDS (channel rows,
 // pair columns) after the 3 + 4 float4 add/sub of the transforms; grid = (Cout/64 x Cin/64 tiles, 3 filter rows, splits
 // of the pair range), fp32 atomics when split.  One workgroup = 64 couts x 64 cins x 4 xi (4 accumulator tiles per wave),
-// K-step 16 pairs, 64 KB LDS (rows of 16 floats, slots XOR-swizzled as in conv_wino.hip; the four quad groups of a wave
+// K-step 16 pairs, 32 KB LDS (both operands register-staged and single-buffered with two barriers per stage -> three
+// workgroups per CU instead of two: +7 %; rows of 16 floats, slots XOR-swizzled as in conv_wino.hip; the four quad groups of a wave
 // write DIFFERENT channel residues in each store round so that the transposing ds_write_b32 stays conflict-free).
 // The bias gradient rides along: sum(e0 + e1) is the xi = 1 component of A e.
 // Power-of-two H and W only (every DDM shape); anything else stays on conv_wgrad.hip.

@@ -12,8 +12,10 @@
 // kernel's own rounding (tests: rtol 1e-3 against the oracle like every other kernel, observed ~1e-6).
 //
 // GEMM view per xi: M' = B*H*W/2 pixel PAIRS, N = Cout, K' = (ky, cin).  One workgroup (4 waves, 2x2) owns 64 pairs x
-// 64 couts for ALL four xi (4 accumulator tiles per wave = 64 AGPRs, like the direct kernel); K-step 16, double
-// buffered: 2 x (4 x 64 x 16 + 4 x 64 x 16) floats = 64 KB of LDS -> two workgroups per CU.
+// 64 couts for ALL four xi (4 accumulator tiles per wave = 64 AGPRs, like the direct kernel); K-step 16.  The weight
+// operand is double-buffered (LDS-DMA overlaps the MFMAs), the register-staged pixel operand is SINGLE-buffered with a
+// second barrier per stage: (4 x 64 x 16 + 2 x 4 x 64 x 16) floats = 48 KB of LDS -> three workgroups per CU (the
+// register limit) instead of two, which is worth +3 % (the extra wave per SIMD fills the barrier and transform gaps).
 //   A: thread = (pair, 16-byte channel quad): four raw buffer loads d0..d3 (range check = zero padding), four float4
 //      add/sub, four ds_write_b128 (rows of 64 B, slots XOR-swizzled with (row >> 2) & 3: conflict-free fragment reads)
 //   B: transformed weights Wq[xi][n][ky][cin] straight to LDS by LDS-DMA (same swizzle on the source address)
