@@ -15,50 +15,81 @@ namespace {
 __host__ __device__ inline int gn_rows_par(int C) { int r = 256 / (C / 4); return r < 1 ? 1 : r; }
 
 // ---------------------------------------------------------------- forward: moments
+// Numerically robust moments ("Welford / two-pass"): every thread accumulates SHIFTED sums
+// s1 = sum(x - K), s2 = sum((x - K)^2) with K = the first value it sees per channel, so s2 - s1^2/n has no catastrophic
+// cancellation for data with |mean| >> std (the plain E[x^2] - mean^2 form loses log2(mean^2/var) bits in fp32); the
+// per-thread (n, mean, M2) triples are merged exactly in fp64, in a fixed order (deterministic).
+// Exact merge of sub-populations (n_i, mean_i, M2_i):  N = sum n_i,  mean = sum n_i mean_i / N,
+// M2 = sum [M2_i + n_i (mean_i - mean)^2]  -- two passes over the (few) partials, one division.
 __global__ void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int HW, int C, int G,
                                   int rows_per_split) {
-  extern __shared__ float sm[];          // [R][C][2]
+  extern __shared__ float sm[];          // [R][C][3] : K, s1, s2
   const int C4 = C >> 2, R = blockDim.x / C4;
   const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
   const int b = blockIdx.x, s = blockIdx.y, S = gridDim.y;
   const int hw0 = s * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
   const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
-  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, K = {0, 0, 0, 0};
+  if (hw0 + ry < hw1) K = xb[(long)(hw0 + ry) * C4 + cq];
 #pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
-    f32x4 v = xb[(long)hw * C4 + cq];
+    f32x4 v = xb[(long)hw * C4 + cq] - K;
     s1 += v;
     s2 += v * v;
   }
-  float* p1 = sm + (ry * C + cq * 4) * 2;
+  float* p1 = sm + (ry * C + cq * 4) * 3;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { p1[2 * k] = s1[k]; p1[2 * k + 1] = s2[k]; }
+  for (int k = 0; k < 4; ++k) { p1[3 * k] = K[k]; p1[3 * k + 1] = s1[k]; p1[3 * k + 2] = s2[k]; }
   __syncthreads();
   const int cpg = C / G;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    double a = 0.0, q = 0.0;
-    for (int r = 0; r < R; ++r)
+    double N = 0.0, sum = 0.0;
+    for (int r = 0; r < R; ++r) {
+      const int first = hw0 + r;
+      if (first >= hw1) break;
+      const double n = (double)((hw1 - first + R - 1) / R);      // rows thread-row r visited
+      double a = 0.0;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += (double)sm[(r * C + c) * 3] * n + (double)sm[(r * C + c) * 3 + 1];
+      sum += a; N += n * cpg;
+    }
+    const double mean = N > 0.0 ? sum / N : 0.0;
+    double m2 = 0.0;
+    for (int r = 0; r < R; ++r) {
+      const int first = hw0 + r;
+      if (first >= hw1) break;
+      const double n = (double)((hw1 - first + R - 1) / R), inv_n = 1.0 / n;
       for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        a += (double)sm[(r * C + c) * 2];
-        q += (double)sm[(r * C + c) * 2 + 1];
+        const float* q = sm + (r * C + c) * 3;
+        const double a = (double)q[1], mt = (double)q[0] + a * inv_n, d = mt - mean;
+        m2 += ((double)q[2] - a * a * inv_n) + n * d * d;
       }
+    }
     double* o = ws + (((long)b * S + s) * G + g) * 2;
-    o[0] = a; o[1] = q;
+    o[0] = mean; o[1] = m2;
   }
 }
 
 __global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int BG, int G, int S,
-                                   double inv_n, float eps) {
+                                   int HW, int rows_per_split, int cpg, float eps) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*G + g
   if (i >= BG) return;
   int b = i / G, g = i - b * G;
-  double a = 0.0, q = 0.0;
+  double N = 0.0, sum = 0.0;
   for (int s = 0; s < S; ++s) {
-    const double* o = ws + (((long)b * S + s) * G + g) * 2;
-    a += o[0]; q += o[1];
+    const int hw0 = s * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
+    const double n = (double)max(hw1 - hw0, 0) * cpg;
+    sum += n * ws[(((long)b * S + s) * G + g) * 2]; N += n;
   }
-  double mean = a * inv_n;
-  double var = q * inv_n - mean * mean;
+  const double mean = sum / N;
+  double m2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const int hw0 = s * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
+    const double n = (double)max(hw1 - hw0, 0) * cpg;
+    const double* o = ws + (((long)b * S + s) * G + g) * 2;
+    const double d = o[0] - mean;
+    if (n > 0.0) m2 += o[1] + n * d * d;
+  }
+  double var = m2 / N;
   if (var < 0.0) var = 0.0;
   stats[2 * i] = (float)mean;
   stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -288,24 +319,40 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
     v[i] = f32x4{0, 0, 0, 0};
     if (hw < HW) v[i] = xb[(long)hw * C4 + cq];
   }
+  // the slab is in registers: a true two-pass per thread (own mean first, then squared deviations), merged in fp64
+  int nrow = 0;
 #pragma unroll
-  for (int i = 0; i < MAXR; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+  for (int i = 0; i < MAXR; ++i)
+    if (ry + i * R < HW) { s1 += v[i]; ++nrow; }
+  const float inv_rows = nrow ? 1.f / (float)nrow : 0.f;
+  const f32x4 tm = s1 * inv_rows;
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i)
+    if (ry + i * R < HW) { const f32x4 d = v[i] - tm; s2 += d * d; }
   float* p1 = sm + (ry * Cc + cq * 4) * 2;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { p1[2 * k] = s1[k]; p1[2 * k + 1] = s2[k]; }
+  for (int k = 0; k < 4; ++k) { p1[2 * k] = tm[k]; p1[2 * k + 1] = s2[k]; }
   __syncthreads();
   float* gs = sm + R * Cc * 2;
   if ((int)threadIdx.x < Gc) {
     const int g = threadIdx.x;
-    double a = 0.0, q = 0.0;
-    for (int r = 0; r < R; ++r)
+    double N = 0.0, sum = 0.0;
+    for (int r = 0; r < R && r < HW; ++r) {
+      const double n = (double)((HW - r + R - 1) / R);
+      double a = 0.0;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += (double)sm[(r * Cc + c) * 2];
+      sum += a * n; N += n * cpg;
+    }
+    const double mean = sum / N;
+    double m2 = 0.0;
+    for (int r = 0; r < R && r < HW; ++r) {
+      const double n = (double)((HW - r + R - 1) / R);
       for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        a += (double)sm[(r * Cc + c) * 2];
-        q += (double)sm[(r * Cc + c) * 2 + 1];
+        const double d = (double)sm[(r * Cc + c) * 2] - mean;
+        m2 += (double)sm[(r * Cc + c) * 2 + 1] + n * d * d;
       }
-    const double inv_n = 1.0 / ((double)HW * cpg);
-    const double mean = a * inv_n;
-    double var = q * inv_n - mean * mean;
+    }
+    double var = m2 / N;
     if (var < 0.0) var = 0.0;
     const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
     gs[2 * g] = m; gs[2 * g + 1] = rs;
@@ -477,10 +524,10 @@ extern "C" int adm_gn_stats(const float* x, float* stats, double* ws, int B, int
                             hipStream_t stream) {
   if (!x || !stats || !ws || !gn_shape_ok(B, HW, C, G)) return ADM_EINVAL;
   int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S), R = gn_rows_par(C);
-  size_t smem = (size_t)R * C * 2 * sizeof(float);
+  size_t smem = (size_t)R * C * 3 * sizeof(float);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(B, S), dim3(gn_threads(C)), smem, stream, x, ws, HW, C, G, rows);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(adm_cdiv(B * G, 256)), dim3(256), 0, stream, ws, stats, B * G, G, S,
-                     1.0 / ((double)HW * (C / G)), eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(adm_cdiv(B * G, 256)), dim3(256), 0, stream, ws, stats, B * G, G, S, HW,
+                     rows, C / G, eps);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -172,7 +172,9 @@ class LatentDiffusion(DDPM):
             C, noise = self.model(img, t_vec)
             z = (epsilons[k].to(device=dev, dtype=torch.float64) if epsilons is not None
                  else torch.randn(shape, device=dev, dtype=torch.float64)).contiguous()
-            ops.sampler_step_stochastic(img, C, noise, z, t_vec, s_vec, self._sched, False, 1.0, False)
+            # scale_by_softsign: the predicted x0 is clamped to +-0.987654321 before C is re-derived (ddm_const_2.py:661-665)
+            ops.sampler_step_stochastic(img, C, noise, z, t_vec, s_vec, self._sched, bool(self.scale_by_softsign),
+                                        0.987654321 if self.scale_by_softsign else 1.0, False)
             cur = cur - s
         if self.scale_by_softsign:
             img.clamp_(-0.987654321, 0.987654321)

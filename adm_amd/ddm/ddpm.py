@@ -207,6 +207,12 @@ class DDPMBase(nn.Module):
         cache[key] = ent
         return ent
 
+    def _start_noise(self, shape, dev):
+        """x_T of the samplers: N(0,1) or U(-1,1) by ``start_dist`` (ddm_const_2.py:305-310, 353-358)."""
+        if self.start_dist == "normal":
+            return torch.randn(shape, device=dev, dtype=torch.float64)
+        return 2 * torch.rand(shape, device=dev, dtype=torch.float64) - 1.0
+
     def t_steps(self):
         n = self.sampling_timesteps
         i = torch.arange(n, dtype=torch.float64)
@@ -234,7 +240,7 @@ class DDPMBase(nn.Module):
         dev = self.eps.device
         ts = self.t_steps()
         if x_T is None:
-            x_T = torch.randn(shape, device=dev, dtype=torch.float64)
+            x_T = self._start_noise(shape, dev)
         x = (x_T.to(device=dev, dtype=torch.float64) * float(ts[0])).contiguous()
         clip = self.clip_x_start and self.SCHEDULE == "const"     # const_2's deterministic sampler never clamps x0
         traj = []
@@ -259,6 +265,8 @@ class DDPMBase(nn.Module):
             ops.sampler_step(x, C, noise, t_cur, t_next, self._sched, clip, float(self.scale_input), last)
             if return_traj and not last:
                 traj.append(x.clone())
+        if g is not None:           # x is the graph's static input buffer: the next sample() of this shape overwrites it
+            x = x.clone()
         return (x, traj) if return_traj else x
 
     @torch.no_grad()
@@ -274,7 +282,7 @@ class DDPMBase(nn.Module):
         steps = (-torch.diff(ts)).tolist()
         B = shape[0]
         if x_T is None:
-            x_T = torch.randn(shape, device=dev, dtype=torch.float64)
+            x_T = self._start_noise(shape, dev)
         img = x_T.to(device=dev, dtype=torch.float64).contiguous()
         if self.SCHEDULE != "const":
             img = img * self.sigma_max

@@ -72,6 +72,7 @@ class BucketedGradReducer:
         self.active = dist.is_initialized() and (self.world > 1 or force)
         self.cuda = flat.grad.is_cuda
         self.side = torch.cuda.Stream() if (self.cuda and self.active) else None
+        self.main = torch.cuda.current_stream() if self.cuda else None       # the stream backward() is called on
         self.buckets = []             # (start, end, n_params)
         self.param_bucket = {}
         cap = max(1, bucket_bytes // 4)
@@ -121,6 +122,11 @@ class BucketedGradReducer:
             ev.record()
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
+                # the hook may fire on the weight-gradient side stream (ops.SIDE_WGRAD) while other gradients of this
+                # bucket were written on the main stream, or the other way round: order the all-reduce after BOTH
+                if ops._side_stream is not None:
+                    self.side.wait_stream(ops._side_stream)
+                self.side.wait_stream(self.main)
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)

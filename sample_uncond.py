@@ -32,13 +32,17 @@ def load_weights(model, path, use_ema, device):
     if "model" in data and "scale_factor" in data["model"] and hasattr(model, "scale_factor"):     # reference :146-147
         model.scale_factor = data["model"]["scale_factor"].to(device)
     missing, unexpected = model.load_state_dict(sd, strict=False)
-    print(f"loaded {path}: {len(missing)} missing, {len(unexpected)} unexpected keys")
+    matched = len(sd) - len(unexpected)
+    print(f"loaded {path}: {matched} tensors matched, {len(missing)} missing, {len(unexpected)} unexpected keys")
+    if matched == 0:
+        raise RuntimeError(f"{path}: none of the checkpoint's {len(sd)} keys matches the model (wrong config or prefix?)")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", required=True)
     ap.add_argument("--max-batches", type=int, default=None)
+    ap.add_argument("--random-init", action="store_true", help="smoke runs: sample without loading a checkpoint")
     args = ap.parse_args()
     with open(args.cfg) as f:
         cfg = Cfg(yaml.load(f, Loader=yaml.SafeLoader))
@@ -50,10 +54,15 @@ def main():
     mc = cfg.model
     dpm = build_model(mc).to(device).eval()          # pixel-space DDPM or LatentDiffusion (+ first stage), reference :50-64
     s = cfg.sampler
-    if s.get("ckpt_path") and os.path.exists(s.ckpt_path):
+    if s.get("ckpt_path") and not args.random_init:
+        if not os.path.exists(s.ckpt_path):
+            raise FileNotFoundError(f"sampler.ckpt_path {s.ckpt_path} does not exist (pass --random-init to sample from "
+                                    "freshly initialised weights)")
         load_weights(dpm, s.ckpt_path, s.get("use_ema", True), device)
+    elif not args.random_init:
+        raise ValueError("sampler.ckpt_path is empty (pass --random-init to sample from freshly initialised weights)")
     else:
-        print("no checkpoint found: sampling from the initialised weights")
+        print("--random-init: sampling from the initialised weights")
     out = s.save_folder
     os.makedirs(out, exist_ok=True)
     from PIL import Image

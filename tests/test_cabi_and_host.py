@@ -112,3 +112,49 @@ def test_lr_and_ema_schedules(golden_dir):
         assert abs(ema_decay_at(int(s)) - d) < 1e-12
     for i, r in zip(g9["lr_its"], g9["lr_ratio"]):
         assert abs(lr_lambda(int(i), 1e-4, 5e-6, 800000) - r) < 1e-12
+
+
+def test_image_stream_never_trains_on_noise_silently(tmp_path):
+    """a data section that names a real dataset must load it or raise; U(-1,1) noise only for 'synthetic'."""
+    import pickle
+    from train_uncond_dpm import ImageStream
+    dev = torch.device("cpu")
+    s = ImageStream({"class_name": "synthetic"}, 4, (32, 32), dev, 0)
+    assert next(s)["image"].shape == (4, 3, 32, 32)
+    with pytest.raises(NotImplementedError):
+        ImageStream({"class_name": "ddm.data.CelebAHQ", "img_folder": "/x"}, 4, (32, 32), dev, 0)
+    with pytest.raises(NotImplementedError):
+        ImageStream({}, 4, (32, 32), dev, 0)
+    with pytest.raises(FileNotFoundError):
+        ImageStream({"class_name": "synthetic", "npy": str(tmp_path / "missing.npy")}, 4, (32, 32), dev, 0)
+    np.save(tmp_path / "bad.npy", np.zeros((5, 16, 16, 3), np.uint8))
+    with pytest.raises(ValueError):
+        ImageStream({"npy": str(tmp_path / "bad.npy")}, 4, (32, 32), dev, 0)
+    np.save(tmp_path / "f32.npy", np.zeros((5, 32, 32, 3), np.float32))
+    with pytest.raises(ValueError):
+        ImageStream({"npy": str(tmp_path / "f32.npy")}, 4, (32, 32), dev, 0)
+    arr = (np.arange(6 * 32 * 32 * 3) % 251).astype(np.uint8).reshape(6, 32, 32, 3)
+    np.save(tmp_path / "ok.npy", arr)
+    s = ImageStream({"npy": str(tmp_path / "ok.npy"), "augment_horizontal_flip": False}, 4, (32, 32), dev, 0)
+    b = next(s)["image"]
+    assert b.shape == (4, 3, 32, 32) and float(b.min()) >= -1 and float(b.max()) <= 1
+    # the reference's YAML: class_name ddm.data.CIFAR10 + img_folder with the standard python batches
+    base = tmp_path / "cifar-10-batches-py"
+    base.mkdir()
+    for i in range(1, 6):
+        data = ((np.arange(3 * 3072) + i) % 256).astype(np.uint8).reshape(3, 3072)
+        with open(base / f"data_batch_{i}", "wb") as f:
+            pickle.dump({"data": data, "labels": [0, 1, 2]}, f)
+    s = ImageStream({"class_name": "ddm.data.CIFAR10", "img_folder": str(tmp_path)}, 4, (32, 32), dev, 0)
+    assert s.images.shape == (15, 3, 32, 32)
+    first = ((np.arange(3072) + 1) % 256).astype(np.float32).reshape(3, 32, 32) / 127.5 - 1      # CHW planes, data.py:96-97
+    np.testing.assert_allclose(s.images[0].numpy(), first, atol=1e-6)
+    with pytest.raises(FileNotFoundError):
+        ImageStream({"class_name": "ddm.data.CIFAR10", "img_folder": str(tmp_path / "nowhere")}, 4, (32, 32), dev, 0)
+
+
+def test_warmup_iter_is_configurable():
+    from adm_amd.optim import lr_lambda
+    assert lr_lambda(99, 1e-4, 5e-6, 1000, warmup=100) == 1.0
+    assert lr_lambda(49, 1e-4, 5e-6, 1000, warmup=100) == 0.5
+    assert abs(lr_lambda(600, 1e-4, 5e-6, 1000, warmup=100) - 0.5 ** 0.96) < 1e-12

@@ -9,6 +9,8 @@ import torch
 
 from oracle import augment_ref as A, fill
 
+from parity import close  # noqa: E402  (tests/parity.py: the north_star tolerance, elementwise)
+
 pytestmark = pytest.mark.gpu
 KW = dict(xflip=1e8, yflip=1, scale=1, rotate_frac=1, aniso=1, translate_frac=1)
 
@@ -20,12 +22,6 @@ def gpu():
     from adm_amd import hip
     hip.lib()
     return torch.device("cuda:0")
-
-
-def close(got, want, rtol=1e-3, atol=1e-4):
-    got, want = got.detach().cpu().double(), torch.as_tensor(np.asarray(want)).double()
-    s = max(float(want.abs().max()), 1e-12)
-    torch.testing.assert_close(got / s, want / s, rtol=rtol, atol=atol)
 
 
 @pytest.mark.parametrize("tag,p,N,H,W,seed,force", [("p012", 0.12, 16, 32, 32, 11, 0.0), ("p015", 0.15, 16, 32, 32, 12, 0.0),

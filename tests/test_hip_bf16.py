@@ -70,6 +70,26 @@ def test_conv_bf16_forward_backward(ops_bf16, cin, cout, H, ks, up):
     torch.testing.assert_close(bd.grad.cpu(), gy.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4 * float(gy.sum(dim=(0, 2, 3)).abs().max()))
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(1, 64, 64, 1, 2), (1, 64, 128, 2, 2), (2, 128, 64, 1, 1), (3, 64, 64, 3, 5)])
+def test_conv_bf16_tiny_images(ops_bf16, B, cin, cout, H, W):
+    """Edge cases of the bf16 forward / data-gradient / weight-gradient kernels: images smaller than the filter (the
+    shifted buffer descriptor of the weight-gradient kernels must clamp at 0: round-1 fault, conv_wgrad_bf16.hip:51)."""
+    ops = ops_bf16
+    x = fill.hash_tensor((B, cin, H, W), f"tx{cin}{cout}{H}{W}", 1.0)
+    w = fill.hash_tensor((cout, cin, 3, 3), f"tw{cin}{cout}", 1.0 / math.sqrt(cin * 9))
+    gy = fill.hash_tensor((B, cout, H, W), f"tg{cin}{cout}{H}{W}", 1.0)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    y = ops.conv2d(xd, wd, None, None)
+    (y * gy.permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    xr, wr = r16(x).requires_grad_(True), r16(w).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, padding=1)
+    yr.backward(r16(gy))
+    torch.testing.assert_close(y.detach().cpu().permute(0, 3, 1, 2), yr.detach(), rtol=2e-4, atol=2e-4 * float(yr.abs().max()))
+    torch.testing.assert_close(xd.grad.cpu().permute(0, 3, 1, 2), xr.grad, rtol=2e-4, atol=2e-4 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=2e-4, atol=3e-4 * float(wr.grad.abs().max()))
+
+
 def test_unet_bf16_vs_f32_end_to_end(ops_bf16):
     ops = ops_bf16
     from adm_amd.unet.uncond_unet import EDMPrecond

@@ -11,6 +11,8 @@ import torch.nn.functional as F
 
 from oracle import ae_ref, fill, unet_ref
 
+from parity import close  # noqa: E402  (tests/parity.py: the north_star tolerance, elementwise)
+
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-3, 1e-4
 
@@ -22,13 +24,6 @@ def gpu():
     from adm_amd import hip
     hip.lib()
     return torch.device("cuda:0")
-
-
-def close(got, want, scale=None, rtol=RTOL, atol=ATOL):
-    got = got.detach().cpu().double()
-    want = torch.as_tensor(np.asarray(want)).double()
-    s = max(float(want.abs().max()) if scale is None else scale, 1e-12)
-    torch.testing.assert_close(got / s, want / s, rtol=rtol, atol=atol)
 
 
 def nhwc(x, cpad):

@@ -9,6 +9,8 @@ import torch
 
 from oracle import ddm_ref, fill, unet_ref
 
+from parity import close  # noqa: E402  (tests/parity.py: the north_star tolerance, elementwise)
+
 pytestmark = pytest.mark.gpu
 SMALL = dict(model_channels=64, num_blocks=1, dropout=0.0)
 RTOL, ATOL = 1e-3, 1e-4
@@ -21,13 +23,6 @@ def gpu():
     from adm_amd import hip
     hip.lib()
     return torch.device("cuda:0")
-
-
-def close(got, want, scale=None, rtol=RTOL, atol=ATOL):
-    got = got.detach().cpu().double()
-    want = torch.as_tensor(np.asarray(want)).double()
-    s = max(float(want.abs().max()) if scale is None else scale, 1e-12)
-    torch.testing.assert_close(got / s, want / s, rtol=rtol, atol=atol)
 
 
 def build_unet(variant, gpu, full=False, **over):
@@ -127,6 +122,49 @@ def test_full_width_cifar_model_vs_golden(gpu, golden_dir):
     with torch.no_grad():
         dx, dy = m(x.to(gpu), sigma.to(gpu), augment_labels=aug.to(gpu))
     close(dx, g["D_x"]); close(dy, g["D_y"])
+
+
+G2_CLASSES = [  # cin, cout, Hin, up, down, attn  (tools/make_golden.py BLOCK_CLASSES)
+    (192, 192, 32, 0, 0, 0), (384, 192, 32, 0, 0, 0), (576, 192, 32, 0, 0, 0), (384, 384, 16, 1, 0, 0),
+    (192, 192, 32, 0, 1, 0), (192, 384, 16, 0, 0, 1), (384, 384, 16, 0, 0, 1), (576, 384, 16, 0, 0, 1),
+    (768, 384, 16, 0, 0, 1), (384, 384, 8, 1, 0, 0), (384, 384, 16, 0, 1, 0), (384, 384, 8, 0, 0, 1),
+    (768, 384, 8, 0, 0, 1), (384, 384, 4, 1, 0, 0), (384, 384, 8, 0, 1, 0), (384, 384, 4, 0, 0, 0),
+    (384, 384, 4, 0, 0, 1), (768, 384, 4, 0, 0, 0)]
+
+
+@pytest.mark.parametrize("winograd", [False, True])
+@pytest.mark.parametrize("cls", G2_CLASSES, ids=lambda c: "blk_%d_%d_%d_%d%d%d" % c)
+def test_unet_block_full_width_vs_reference_golden(gpu, golden_dir, monkeypatch, cls, winograd):
+    """SURVEY's G2: each of the 18 UNetBlock classes of the CIFAR network at FULL channel width, forward, input gradient
+    and conv1 weight-gradient norm, against the vectors the imported reference produced (tests/golden/g2_blocks.npz).
+    winograd=True forces every eligible 3x3 conv (forward, data gradient AND weight gradient) through the Winograd kernels,
+    which at the fixture's B=1 would otherwise stay on the direct kernels."""
+    from adm_amd import ops
+    from adm_amd.unet.dhariwal import UNetBlock
+    monkeypatch.setattr(ops, "WINOGRAD", winograd)
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    g = np.load(os.path.join(golden_dir, "g2_blocks.npz"))
+    cin, cout, hin, up, down, attn = cls
+    name = "blk_%d_%d_%d_%d%d%d" % cls
+    import math
+    init = dict(init_mode="kaiming_uniform", init_weight=math.sqrt(1 / 3), init_bias=math.sqrt(1 / 3))
+    blk = UNetBlock(in_channels=cin, out_channels=cout, emb_channels=768, up=bool(up), down=bool(down), attention=bool(attn),
+                    channels_per_head=64, dropout=0.0, init=init,
+                    init_zero=dict(init_mode="kaiming_uniform", init_weight=0, init_bias=0)).eval()
+    blk.load_state_dict({k: fill.fill_value(name + "." + k, tuple(v.shape)) for k, v in blk.state_dict().items()})
+    blk = blk.to(gpu)
+    x = fill.hash_tensor((1, cin, hin, hin), name + ".x", 1.0)
+    emb = fill.hash_tensor((1, 768), name + ".emb", 1.0)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu).requires_grad_(True)
+    y = blk(xd, emb.to(gpu))
+    y_nchw = y.permute(0, 3, 1, 2)
+    close(y_nchw.reshape(-1)[::7], g[name + ".y"])
+    gy = fill.hash_tensor(tuple(y_nchw.shape), name + ".gy", 1.0)
+    (y * gy.permute(0, 2, 3, 1).contiguous().to(gpu)).sum().backward()
+    close(xd.grad.permute(0, 3, 1, 2).reshape(-1)[::7], g[name + ".dx"])
+    want = float(g[name + ".dconv1_norm"])
+    got = float(blk.conv1.weight.grad.double().norm())
+    assert abs(got - want) <= 1e-3 * want, (got, want)
 
 
 def make_ddpm(sched, gpu):
@@ -296,6 +334,11 @@ def test_sampler_hip_graph_replay_equals_eager(gpu, monkeypatch):
     eager = dpm.sample(batch_size=3, x_T=xT)
     monkeypatch.setenv("ADM_SAMPLE_GRAPH", "1")
     g1 = dpm.sample(batch_size=3, x_T=xT)
+    g1_copy = g1.clone()
+    g2 = dpm.sample(batch_size=3, x_T=xT * 0.5)
+    # the returned tensor must not alias the graph's static input buffer -- a second call of the same shape
+    # would overwrite the first result in place
+    assert g1.data_ptr() != g2.data_ptr() and torch.equal(g1, g1_copy) and not torch.equal(g1, g2)
     g2 = dpm.sample(batch_size=3, x_T=xT)
     assert torch.equal(eager, g1) and torch.equal(eager, g2)
     assert len(dpm._graphs) == 1

@@ -10,6 +10,8 @@ import torch.nn.functional as F
 
 from oracle import fill, unet_ref
 
+from parity import close  # noqa: E402  (tests/parity.py: the north_star tolerance, elementwise)
+
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-3, 1e-4
@@ -34,13 +36,6 @@ def nhwc(t):
 
 def nchw(t):
     return t.detach().cpu().permute(0, 3, 1, 2)
-
-
-def close(got, want, scale=None, rtol=RTOL, atol=ATOL):
-    got, want = got.detach().cpu().double(), want.detach().cpu().double()
-    s = float(want.abs().max()) if scale is None else scale
-    s = max(s, 1e-12)
-    torch.testing.assert_close(got / s, want / s, rtol=rtol, atol=atol)
 
 
 def pad_c(t, c):
@@ -121,6 +116,38 @@ def test_conv_winograd_forward_backward(ops, monkeypatch, B, cin, cout, H, W, up
     with torch.no_grad():
         yd = ops.conv2d(xd.detach(), dev(w), dev(b), rd.detach(), up=up)
     assert float((y.detach() - yd).abs().max()) <= 1e-5 * float(yd.abs().max())
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,up,force", [
+    (8, 64, 96, 32, 32, False, False),      # M = 8192: the Winograd weight-gradient kernel is selected BY DEFAULT
+    (8, 96, 64, 16, 16, True, False),       # fused nearest x2 (decoder up-conv): grid 32x32, M = 8192, default selection
+    (2, 192, 192, 32, 32, False, True),     # channel counts of the CIFAR network
+    (1, 32, 32, 1, 2, False, True),         # the 1x2 image that faulted in round 1 (negative shifted descriptor size)
+    (1, 32, 64, 2, 2, False, True), (3, 3, 32, 2, 4, False, True), (2, 32, 32, 1, 1, True, True)])
+def test_conv_wgrad_winograd_op_level(ops, monkeypatch, B, cin, cout, H, W, up, force):
+    """wgrad_wino_kernel (F(3,2) weight gradient + fused bias gradient) on its own against F.conv2d's autograd on the CPU:
+    shapes that select it by default plus tiny-image edge cases.  The launch record proves which kernel ran."""
+    if force:
+        monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    x = fill.hash_tensor((B, cin, H, W), f"gwx{cin}{cout}{H}", 1.0)
+    w = fill.hash_tensor((cout, cin, 3, 3), f"gww{cin}{cout}", 1.0 / math.sqrt(cin * 9))
+    b = fill.hash_tensor((cout,), f"gwb{cin}{cout}", 0.5)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    gy = fill.hash_tensor((B, cout, Ho, Wo), f"gwg{cin}{cout}{H}", 1.0)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    (F.conv2d(xin, wr, br, padding=1) * gy).sum().backward()
+    cip, cop = ops.ceil32(cin), ops.ceil32(cout)
+    xd = nhwc(pad_c(x, cip))
+    wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    monkeypatch.setattr(ops, "PROFILE", [])
+    y = ops.conv2d(xd, wd, bd, None, up=up)
+    (y * nhwc(pad_c(gy, cop))).sum().backward()
+    kinds = [r[0] for r in ops.PROFILE]
+    assert "wgrad_wino" in kinds and "wgrad" not in kinds, kinds
+    close(wd.grad, wr.grad)
+    close(bd.grad, br.grad)
 
 
 def test_linear_split_k_is_deterministic(ops):

@@ -57,7 +57,12 @@ def test_group_norm_affine_invariance_full_size(ops, H, C):
     gam, bet = 1 + rnd((C,), 8, 0.2), rnd((C,), 9, 0.1)
     y = ops.group_norm_act(x, gam, bet, None, silu=False)
     y2 = ops.group_norm_act(3.0 * x + 5.0, gam, bet, None, silu=False)       # per-group shift/scale invariance
-    torch.testing.assert_close(y2, y, rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(y2, y, rtol=1e-3, atol=1e-4)
+    # a mean 1000x the spread: the shifted-sum / exact-merge moments (groupnorm.hip) must not lose the variance, which the
+    # one-pass E[x^2] - mean^2 form does in fp32 (Welford / two-pass)
+    xs = x[:8]
+    y3 = ops.group_norm_act(xs + 2000.0, gam, bet, None, silu=False)
+    torch.testing.assert_close(y3, y[:8], rtol=1e-3, atol=2e-3)      # the input itself carries only ~2e-4 absolute precision at 2000
     G = min(32, C // 4)
     z = ((y - bet) / gam).reshape(B, H * H, G, C // G)
     assert float(z.mean(dim=(1, 3)).abs().max()) < 1e-4

@@ -14,8 +14,9 @@ What differs: one process per GPU with torch.distributed/RCCL instea
 optimiser state lives in flat buffers driven by the fused HIP kernel (so 'opt' in the checkpoint holds
 {'exp_avg','exp_avg_sq','step'} flat tensors); gradients ARE averaged across ranks (the reference
 bypasses DDP.forward and never synchronises them); images/sec is logged.
-Datasets are not shipped: ``data.class_name: synthetic`` (default when the folder is missing) draws
-U(-1,1) images; ``data.npy`` may point at a uint8 [N,32,32,3] .npy file.
+Datasets are not shipped: ``data.class_name: synthetic`` draws U(-1,1) images (benchmarking only); ``data.npy`` may point
+at a uint8 [N,32,32,3] .npy file; ``ddm.data.CIFAR10`` + ``img_folder`` reads the standard python batches.  Any other
+data section raises instead of training on noise.
 """
 import argparse
 import os
@@ -55,23 +56,72 @@ def parse_args():
     return args
 
 
+def _load_cifar10_batches(folder):
+    """uint8 [50000,32,32,3] from ``<folder>/cifar-10-batches-py/data_batch_{1..5}`` (the layout ddm.data.CIFAR10 reads,
+    /root/reference/ddm/data.py:61-98).  The batches are pickled dicts of numpy arrays and python lists; the unpickler below
+    resolves nothing except numpy's array reconstructors."""
+    import pickle
+
+    class _NumpyOnly(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] == "numpy" and name in ("_reconstruct", "ndarray", "dtype", "scalar", "_frombuffer"):
+                return super().find_class(module, name)
+            if module in ("numpy.core.multiarray", "numpy._core.multiarray") and name == "_reconstruct":
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a dataset file")
+
+    base = os.path.join(folder, "cifar-10-batches-py")
+    parts = []
+    for i in range(1, 6):
+        path = os.path.join(base, f"data_batch_{i}")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"data.img_folder: {path} does not exist")
+        with open(path, "rb") as f:
+            parts.append(np.asarray(_NumpyOnly(f, encoding="latin1").load()["data"], dtype=np.uint8))
+    return np.vstack(parts).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1)
+
+
 class ImageStream:
-    """Infinite iterator of {'image': [B,3,H,W] in [-1,1]} on the GPU (the batch-dict shape of ddm.data.CIFAR10)."""
+    """Infinite iterator of {'image': [B,3,H,W] in [-1,1]} on the GPU (the batch-dict shape of ddm.data.CIFAR10).
+
+    Sources, in this order: ``data.npy`` (uint8 [N,H,W,3]; must exist and match ``image_size``); ``data.class_name:
+    ddm.data.CIFAR10`` + ``img_folder`` (the reference YAML, /root/reference/configs/cifar10/*.yaml); ``data.class_name:
+    synthetic`` = U(-1,1) images.  Anything else raises: a config that names a real dataset never trains on noise silently."""
 
     def __init__(self, data_cfg, batch, image_size, device, seed):
-        self.batch, self.size, self.device = batch, image_size, device
+        self.batch, self.size, self.device = batch, tuple(image_size), device
         self.gen = torch.Generator(device=device).manual_seed(seed)
         self.images = None
-        path = data_cfg.get("npy") if data_cfg else None
-        if path and os.path.exists(path):
-            arr = np.load(path, allow_pickle=False)          # uint8 [N,H,W,3]
-            self.images = torch.from_numpy(arr).to(device).permute(0, 3, 1, 2).float() / 127.5 - 1.0
+        data_cfg = data_cfg or {}
+        path, cls = data_cfg.get("npy"), data_cfg.get("class_name")
+        self.flip = bool(data_cfg.get("augment_horizontal_flip", True))
+        arr = None
+        if path:
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"data.npy: {path} does not exist")
+            arr = np.load(path, allow_pickle=False)
+        elif cls in ("ddm.data.CIFAR10", "CIFAR10"):
+            if not data_cfg.get("img_folder"):
+                raise ValueError("data.class_name ddm.data.CIFAR10 needs data.img_folder")
+            arr = _load_cifar10_batches(data_cfg.get("img_folder"))
+        elif cls != "synthetic":
+            raise NotImplementedError(f"data.class_name {cls!r}: only ddm.data.CIFAR10, a uint8 data.npy, or 'synthetic' "
+                                      "(U(-1,1) images, benchmarking only) are implemented")
+        if arr is not None:
+            if arr.dtype != np.uint8 or arr.ndim != 4 or arr.shape[-1] != 3 or tuple(arr.shape[1:3]) != self.size:
+                raise ValueError(f"image array must be uint8 [N,{self.size[0]},{self.size[1]},3], got {arr.dtype} {arr.shape}")
+            self.images = torch.from_numpy(np.ascontiguousarray(arr)).to(device).permute(0, 3, 1, 2).float() / 127.5 - 1.0
+
+    def __iter__(self):
+        return self
 
     def __next__(self):
         if self.images is None:
             return {"image": torch.rand(self.batch, 3, *self.size, device=self.device, generator=self.gen) * 2 - 1}
         idx = torch.randint(0, self.images.shape[0], (self.batch,), device=self.device, generator=self.gen)
         x = self.images[idx]
+        if not self.flip:
+            return {"image": x}
         flip = torch.rand(self.batch, device=self.device, generator=self.gen) < 0.5
         return {"image": torch.where(flip[:, None, None, None], x.flip(-1), x)}
 
@@ -105,13 +155,18 @@ class Trainer:
         self.reducer = BucketedGradReducer(self.flat)
         self.opt = FusedAdamWEMA(self.flat, lr=self.lr, weight_decay=float(t.get("weight_decay", 1e-4)), max_norm=1.0,
                                  ema=(rank == 0))
+        self.warmup_iter = int(t.get("warmup_iter", 5000))      # train_uncond_dpm.py:170
         self.step = 0
         self.ema_step = 0
+        self.ema_initted = False
         if rank == 0:
             os.makedirs(self.results, exist_ok=True)
         milestone = t.get("resume_milestone", 0)
         if milestone and os.path.exists(os.path.join(self.results, f"model-{milestone}.pt")):
             self.load(milestone)
+
+    def _lr_ratio(self, it):
+        return lr_lambda(it, self.lr, self.min_lr, self.train_num_steps, self.warmup_iter)
 
     # ---- checkpoint layout of train_uncond_dpm.py:207-239 --------------------------------------
     def ema_state_dict(self):
@@ -122,7 +177,7 @@ class Trainer:
         for n, b in self.model.named_buffers():
             sd["online_model." + n] = b.clone()
             sd["ema_model." + n] = b.clone()
-        sd["initted"] = torch.tensor([self.step > self.ema_after])
+        sd["initted"] = torch.tensor([self.ema_initted])
         sd["step"] = torch.tensor([self.ema_step])
         return sd
 
@@ -149,6 +204,7 @@ class Trainer:
                 if "ema_model." + n in data["ema"]:
                     self.opt.ema[o:o + p.numel()].copy_(data["ema"]["ema_model." + n].reshape(-1))
             self.ema_step = int(data["ema"].get("step", torch.tensor([0]))[0])
+            self.ema_initted = bool(data["ema"].get("initted", torch.tensor([False]))[0])
         from adm_amd import ops
         ops.invalidate_packed()
 
@@ -175,15 +231,19 @@ class Trainer:
             # EMA.update (ddm/ema.py:153-170): every `update_every` calls; copy until update_after_step
             decay = None
             if self.rank == 0 and self.ema_step % self.ema_every == 0:
-                decay = 0.0 if self.ema_step <= self.ema_after else ema_decay_at(self.ema_step + 1, update_after_step=self.ema_after)
+                if self.ema_step <= self.ema_after:
+                    decay = 0.0                      # copy_params_from_model_to_ema
+                elif not self.ema_initted:           # first update after the warm-up: hard copy (ema.py:153-156, initted False)
+                    decay, self.ema_initted = 0.0, True
+                else:
+                    decay = ema_decay_at(self.ema_step + 1, update_after_step=self.ema_after)
             self.ema_step += 1
-            self.opt.step(lr=self.lr * lr_lambda(self.step, self.lr, self.min_lr, self.train_num_steps),
-                          grad_scale=1.0 / self.world, ema_decay=decay)
+            self.opt.step(lr=self.lr * self._lr_ratio(self.step), grad_scale=1.0 / self.world, ema_decay=decay)
             self.step += 1
             if self.rank == 0 and (self.step % self.log_freq == 0 or self.step == end):
                 dt = time.time() - last
                 print(f"[Train Step] {self.step}/{self.train_num_steps}: loss={loss_acc:.4f} "
-                      f"loss_simple={log_acc.get('train/loss_simple', 0):.5f} lr={self.lr * lr_lambda(self.step, self.lr, self.min_lr, self.train_num_steps):.3e} "
+                      f"loss_simple={log_acc.get('train/loss_simple', 0):.5f} lr={self.lr * self._lr_ratio(self.step):.3e} "
                       f"grad_norm={self.opt.grad_norm(1.0 / self.world):.3f} images/sec={seen / dt:.1f}", flush=True)
                 last, seen = time.time(), 0
             if self.step % self.save_every == 0:
