@@ -27,6 +27,9 @@ struct WgradP {
   const float* x; const float* dy; float* dwp;
   int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes;
   float* dbias;      // optional: dbias[co] += sum_p dY[p][co] (the conv's bias gradient), by the tap-0 / ci-tile-0 workgroups
+  // deterministic mode (split_stride > 0): split z stores its partial tile at dwp + z * split_stride and its bias partial at
+  // dbias + z * bias_stride with plain stores; adm_unpack_wgrad_splits sums the splits in a fixed order
+  long split_stride, bias_stride;
 };
 
 constexpr int WLDS = 36;   // floats per LDS row: 32 pixels + 4 pad
@@ -200,8 +203,13 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], o, 64);
       if (lk == 0 && co0 + a_row[i] < p.Cout) {
+        if (p.split_stride > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&p.dbias[co0 + a_row[i] + j], v[j]);
+          for (int j = 0; j < 4; ++j) p.dbias[(long)blockIdx.z * p.bias_stride + co0 + a_row[i] + j] = v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(&p.dbias[co0 + a_row[i] + j], v[j]);
+        }
       }
     }
   }
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
       for (int r = 0; r < 16; ++r) {
         const int co = cb + (r & 3) + 8 * (r >> 2);
         if (co < p.Cout) {
-          float* dst = p.dwp + ((long)co * taps + tap) * p.Cin + ci;
+          float* dst = p.dwp + (long)blockIdx.z * p.split_stride + ((long)co * taps + tap) * p.Cin + ci;
           if (p.atomic) atomicAdd(dst, acc[i][j][r]);
           else *dst = acc[i][j][r];
         }
@@ -239,21 +247,20 @@ int launch_wgrad(WgradP p, int splits, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
-                              int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
-  return adm_conv_wgrad_bias(x, dy, dwp, nullptr, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, stream);
-}
-
-extern "C" int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
-                                   int ldx, int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
-  if (!x || !dy || !dwp || B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
+namespace {
+// plan_only: return the split count the launcher would pick.  split_stride > 0: deterministic workspace mode.
+int wgrad_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
+               int lddy, int ks, int up, int splits, long split_stride, long bias_stride, bool plan_only, hipStream_t stream) {
+  if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3) || (ks != 1 && ks != 3)) return ADM_EINVAL;
   if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
-  if (((uintptr_t)x | (uintptr_t)dy) & 15) return ADM_EINVAL;
+  if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
   WgradP p;
   p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
   p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.ks = ks; p.up = up; p.tilesN = 0;
+  p.split_stride = split_stride; p.bias_stride = bias_stride;
   const long xb = (long)B * p.Hin * p.Win * ldx * 4, db = (long)p.P * lddy * 4;
   if (xb >= (1L << 31) || db >= (1L << 31)) return ADM_EINVAL;      // 32-bit buffer offsets
   p.xbytes = (int)xb; p.dybytes = (int)db;
@@ -280,8 +287,9 @@ extern "C" int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, 
   }
   int chunk = ((p.P + splits - 1) / splits + 31) & ~31;
   splits = (p.P + chunk - 1) / chunk;
+  if (plan_only) return splits;
   p.chunk = chunk;
-  p.atomic = splits > 1;
+  p.atomic = splits > 1 && split_stride == 0;
   if (p.atomic &&
       hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * ks * ks * Cin, stream) != hipSuccess)
     return ADM_ELAUNCH;
@@ -290,4 +298,35 @@ extern "C" int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, 
   if (TM == 128 && TN == 64) return launch_wgrad<128, 64>(p, splits, stream);
   if (TM == 64 && TN == 128) return launch_wgrad<64, 128>(p, splits, stream);
   return launch_wgrad<64, 64>(p, splits, stream);
+}
+}  // namespace
+
+extern "C" int adm_conv_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
+                              int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
+  return adm_conv_wgrad_bias(x, dy, dwp, nullptr, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, stream);
+}
+
+extern "C" int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
+                                   int ldx, int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
+  return wgrad_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, 0, 0, false, stream);
+}
+
+int adm_wgrad_wino_plan(int B, int H, int W, int Cin, int Cout);      // conv_wgrad_wino.hip
+int adm_wgrad_wino_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
+                      int lddy, int splits, int up, hipStream_t stream);
+
+extern "C" int adm_conv_wgrad_plan(int B, int H, int W, int Cin, int Cout, int ks, int up, int wino) {
+  if (wino) return adm_wgrad_wino_plan(B, H, W, Cin, Cout);
+  return wgrad_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, ks, up, 0, 0, 0, true, nullptr);
+}
+
+extern "C" int adm_conv_wgrad_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx,
+                                 int Cout, int lddy, int ks, int up, int splits, int wino, hipStream_t stream) {
+  if (splits < 1 || !ws) return ADM_EINVAL;
+  if (wino) {
+    if (ks != 3) return ADM_EINVAL;
+    return adm_wgrad_wino_ws(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, up, stream);
+  }
+  return wgrad_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, (long)Cout * ks * ks * Cin, Cout, false,
+                    stream);
 }

@@ -25,6 +25,7 @@ namespace {
 struct WwP {
   const float* x; const float* dy; float* dwp; float* dbias;
   int Pp, H, W, lw, lh, Cin, ldx, Cout, lddy, tilesN, chunk, atomic, xbytes, dybytes;   // Pp = pixel pairs, chunk in pairs
+  long split_stride, bias_stride;      // > 0: deterministic mode, partials of split z at dwp + z * split_stride (plain stores)
 };
 
 constexpr int WT = 64, WKK = 16;       // 64 x 64 channel tile, 16 pairs per stage
@@ -159,8 +160,13 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], o, 64);
     if (lk == 0 && a_col != OOB) {
+      if (p.split_stride > 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) atomicAdd(&p.dbias[co0 + quad * 4 + j], v[j]);
+        for (int j = 0; j < 4; ++j) p.dbias[(long)blockIdx.z * p.bias_stride + co0 + quad * 4 + j] = v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&p.dbias[co0 + quad * 4 + j], v[j]);
+      }
     }
   }
   // ---- epilogue: G^T m.  rows = cout, cols = cin
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
     if (co >= p.Cout) continue;
     const float h = 0.5f * (acc[1][r] + acc[2][r]);
     const float w0 = acc[0][r] + h, w1 = 0.5f * (acc[1][r] - acc[2][r]), w2 = h + acc[3][r];
-    float* dst = p.dwp + ((long)co * 9 + ky * 3) * p.Cin + ci;
+    float* dst = p.dwp + (long)blockIdx.z * p.split_stride + ((long)co * 9 + ky * 3) * p.Cin + ci;
     if (p.atomic) {
       atomicAdd(dst, w0); atomicAdd(dst + p.Cin, w1); atomicAdd(dst + 2 * p.Cin, w2);
     } else {
@@ -186,11 +192,12 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
 
 namespace {
 int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                    int lddy, int splits, int up, hipStream_t stream) {
-  if (!x || !dy || !dwp || B <= 0 || H <= 0 || W < 2) return ADM_EINVAL;
+                    int lddy, int splits, int up, bool det, bool plan_only, hipStream_t stream) {
+  if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
+  if (B <= 0 || H <= 0 || W < 2) return ADM_EINVAL;
   if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
-  if (((uintptr_t)x | (uintptr_t)dy) & 15) return ADM_EINVAL;
+  if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
   auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
   const int lw = ilog2(W), lh = ilog2(H);
   if (lw < 1 || lh < 0) return ADM_EINVAL;                    // power-of-two H, W (W >= 2) only
@@ -220,8 +227,11 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
   }
   int chunk = ((p.Pp + splits - 1) / splits + WKK - 1) / WKK * WKK;
   splits = (p.Pp + chunk - 1) / chunk;
+  if (plan_only) return splits;
   p.chunk = chunk;
-  p.atomic = splits > 1;
+  p.split_stride = det ? (long)Cout * 9 * Cin : 0;
+  p.bias_stride = det ? Cout : 0;
+  p.atomic = splits > 1 && !det;
   if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 9 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
   constexpr int smem = 4 * (WT + WT) * WKK * (int)sizeof(float);
   static bool attr_set = false;
@@ -243,11 +253,21 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
 
 extern "C" int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
                                    int ldx, int Cout, int lddy, int splits, hipStream_t stream) {
-  return wgrad_wino_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, 0, stream);
+  return wgrad_wino_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, 0, false, false, stream);
 }
 
 // Weight gradient of Conv2d(up=True): x is the conv's HALF-resolution input [B][H/2][W/2][ldx]; H x W is dy's grid.
 extern "C" int adm_conv_wgrad_wino_up(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin,
                                       int ldx, int Cout, int lddy, int splits, hipStream_t stream) {
-  return wgrad_wino_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, 1, stream);
+  return wgrad_wino_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, 1, false, false, stream);
+}
+
+// Used by adm_conv_wgrad_plan / adm_conv_wgrad_ws (conv_wgrad.hip): the split count the launcher picks, and the deterministic
+// workspace mode (split z writes its partial tile to ws[z][Cout][9][Cin] and its bias partial to bws[z][Cout]).
+int adm_wgrad_wino_plan(int B, int H, int W, int Cin, int Cout) {
+  return wgrad_wino_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, 0, 0, false, true, nullptr);
+}
+int adm_wgrad_wino_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
+                      int lddy, int splits, int up, hipStream_t stream) {
+  return wgrad_wino_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, up, true, false, stream);
 }

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void spatial_att_bwd_kernel(const float* __res
                                                               const float* __restrict__ h,
                                                               const float* __restrict__ dy, float* __restrict__ dh,
                                                               float* __restrict__ datt, float* __restrict__ dqk,
-                                                              int HW, int C) {
+                                                              float* __restrict__ dqk_part, int HW, int C) {
   __shared__ float a_s[64], g_s[64], av_s[64], dg_s[64], da_s[64], dq_s[64], dk_s[64], p_s[64][65];
   __shared__ float part[256];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -241,8 +241,21 @@ __global__ __launch_bounds__(256) void spatial_att_bwd_kernel(const float* __res
       s0 += dq_s[i] * a_s[i]; s1 += dq_s[i];
       s2 += dk_s[i] * a_s[i]; s3 += dk_s[i];
     }
-    atomicAdd(&dqk[0], s0); atomicAdd(&dqk[1], s1); atomicAdd(&dqk[2], s2); atomicAdd(&dqk[3], s3);
+    if (dqk_part) {          // deterministic: per-image partials, summed in image order by dqk_reduce_kernel
+      float* o = dqk_part + 4 * (long)b;
+      o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+    } else {
+      atomicAdd(&dqk[0], s0); atomicAdd(&dqk[1], s1); atomicAdd(&dqk[2], s2); atomicAdd(&dqk[3], s3);
+    }
   }
+}
+
+__global__ void dqk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dqk, int B) {
+  const int k = threadIdx.x;
+  if (k >= 4) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[4 * (long)b + k];
+  dqk[k] += s;
 }
 
 // ---------------------------------------------------------------- analytic schedule
@@ -371,7 +384,8 @@ __global__ void sampler_step_stochastic_kernel(double* __restrict__ x, const flo
 }
 
 // ---------------------------------------------------------------- optimiser
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, double* __restrict__ out, long n) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, double* __restrict__ out,
+                                                    double* __restrict__ part, long n) {
   __shared__ double red[4];
   float acc = 0.f;
   long n4 = n >> 2;
@@ -384,7 +398,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   double d = wave_sum_d((double)acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const double t = red[0] + red[1] + red[2] + red[3];
+    if (part) part[blockIdx.x] = t; else atomicAdd(out, t);
+  }
+}
+
+// second stage of the deterministic norm: one workgroup sums the per-block partials in a fixed order
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, double* __restrict__ out, int nblocks) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) a += part[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += red[0];
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -597,9 +628,12 @@ extern "C" int adm_spatial_att_fwd(const float* att, int ldatt, const float* qk,
   return ADM_OK;
 }
 extern "C" int adm_spatial_att_bwd(const float* att, int ldatt, const float* qk, const float* h, const float* dy,
-                                   float* dh, float* datt, float* dqk, int B, int HW, int C, hipStream_t stream) {
+                                   float* dh, float* datt, float* dqk, float* dqk_part, int B, int HW, int C,
+                                   hipStream_t stream) {
   if (!att || !qk || !h || !dy || !dh || !datt || !dqk || B <= 0 || HW <= 0 || HW > 64 || (C & 3)) return ADM_EINVAL;
-  hipLaunchKernelGGL(spatial_att_bwd_kernel, dim3(B), dim3(256), 0, stream, att, ldatt, qk, h, dy, dh, datt, dqk, HW, C);
+  hipLaunchKernelGGL(spatial_att_bwd_kernel, dim3(B), dim3(256), 0, stream, att, ldatt, qk, h, dy, dh, datt, dqk, dqk_part, HW,
+                     C);
+  if (dqk_part) hipLaunchKernelGGL(dqk_reduce_kernel, dim3(1), dim3(64), 0, stream, dqk_part, dqk, B);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -620,6 +654,7 @@ extern "C" int adm_ddm_loss(const float* c_pred, const float* n_pred, const floa
   if (hipMemsetAsync(per_sample, 0, sizeof(float) * B, stream) != hipSuccess) return ADM_ELAUNCH;
   int chunks = (int)((n + 1023) / 1024);
   if (chunks > 64) chunks = 64;
+  if (n <= 65536) chunks = 1;          // one workgroup per sample: the reported per-sample sums are bitwise reproducible
   hipLaunchKernelGGL(ddm_loss_kernel, dim3(B, chunks), dim3(256), 0, stream, c_pred, n_pred, x0, noise, w, per_sample,
                      d_c, d_n, gscale, n);
   ADM_CHECK_LAUNCH();
@@ -635,6 +670,7 @@ extern "C" int adm_ddm_loss_latent(const float* c_pred, const float* n_pred, con
   if (hipMemsetAsync(per_l1, 0, sizeof(float) * B, stream) != hipSuccess) return ADM_ELAUNCH;
   int chunks = (int)((n + 1023) / 1024);
   if (chunks > 64) chunks = 64;
+  if (n <= 65536) chunks = 1;
   hipLaunchKernelGGL(ddm_loss_latent_kernel, dim3(B, chunks), dim3(256), 0, stream, c_pred, n_pred, x0, noise, xt, t, w,
                      per_sample, per_l1, d_c, d_n, gscale, n);
   ADM_CHECK_LAUNCH();
@@ -661,9 +697,13 @@ extern "C" int adm_sampler_step_stochastic(double* x, const float* c_pred, const
   return ADM_OK;
 }
 
-extern "C" int adm_sumsq(const float* g, double* sumsq, long n, hipStream_t stream) {
+extern "C" int adm_sumsq_blocks(long n) { return n > 0 ? ew_grid(n, 16) : 0; }
+
+extern "C" int adm_sumsq(const float* g, double* sumsq, double* partials, long n, hipStream_t stream) {
   if (!g || !sumsq || n <= 0 || ((uintptr_t)g & 15)) return ADM_EINVAL;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n, 16)), dim3(256), 0, stream, g, sumsq, n);
+  const int blocks = ew_grid(n, 16);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, stream, g, sumsq, partials, n);
+  if (partials) hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, sumsq, blocks);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

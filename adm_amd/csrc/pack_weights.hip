@@ -55,7 +55,7 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__
 }
 
 __global__ void unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int taps,
-                              int Ci_pad, int qkv, int accumulate) {
+                              int Ci_pad, int qkv, int accumulate, int splits, long split_stride) {
   long total = (long)Co * Ci * taps;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     int tap = idx % taps;
@@ -63,7 +63,9 @@ __global__ void unpack_kernel(const float* __restrict__ dwp, float* __restrict__
     int ci = t % Ci;
     int co = t / Ci;
     int cop = qkv ? qkv_to_packed(co) : co;
-    float v = dwp[((long)cop * taps + tap) * Ci_pad + ci];
+    const long src = ((long)cop * taps + tap) * Ci_pad + ci;
+    float v = dwp[src];
+    for (int z = 1; z < splits; ++z) v += dwp[z * split_stride + src];      // fixed order: deterministic
     dw[idx] = accumulate ? dw[idx] + v : v;
   }
 }
@@ -206,7 +208,37 @@ extern "C" int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int
   int taps = ks * ks;
   long total = (long)Co * Ci * taps;
   int grid = (int)min((long)4096, (total + 255) / 256);
-  hipLaunchKernelGGL(unpack_kernel, dim3(grid), dim3(256), 0, stream, dwp, dw, Co, Ci, taps, Ci_pad, qkv, accumulate);
+  hipLaunchKernelGGL(unpack_kernel, dim3(grid), dim3(256), 0, stream, dwp, dw, Co, Ci, taps, Ci_pad, qkv, accumulate, 1, 0L);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+namespace {
+__global__ void bias_splits_kernel(const float* __restrict__ bws, float* __restrict__ dbias, int n, int splits, long stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = bws[i];
+  for (int z = 1; z < splits; ++z) v += bws[z * stride + i];
+  dbias[i] += v;
+}
+}  // namespace
+
+// Deterministic counterpart of the atomic split reduction: ws[splits][Co_pad][taps][Ci_pad] partial weight gradients (from
+// adm_conv_wgrad_ws) are summed in split order and scattered to OIHW; bws[splits][Co_pad] bias partials are summed into
+// dbias[0..Co_pad) (+=, the packed channel order the atomic path accumulates in).  bws / dbias may be NULL.
+extern "C" int adm_unpack_wgrad_splits(const float* ws, int splits, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad,
+                                       int qkv, int accumulate, const float* bws, float* dbias, hipStream_t stream) {
+  if (!ws || !dw || splits < 1 || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3) || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  if (qkv && (Co % 192 != 0)) return ADM_EINVAL;
+  if ((bws == nullptr) != (dbias == nullptr)) return ADM_EINVAL;
+  int taps = ks * ks;
+  long total = (long)Co * Ci * taps;
+  int grid = (int)min((long)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(unpack_kernel, dim3(grid), dim3(256), 0, stream, ws, dw, Co, Ci, taps, Ci_pad, qkv, accumulate, splits,
+                     (long)Co_pad * taps * Ci_pad);
+  if (bws)
+    hipLaunchKernelGGL(bias_splits_kernel, dim3((Co_pad + 255) / 256), dim3(256), 0, stream, bws, dbias, Co_pad, splits,
+                       (long)Co_pad);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

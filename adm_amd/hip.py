@@ -30,6 +30,9 @@ _SIGS = {
     "adm_conv_wgrad_wino": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bias": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_plan": [I, I, I, I, I, I, I, I],
+    "adm_conv_wgrad_ws": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_unpack_wgrad_splits": [P, I, P, I, I, I, I, I, I, I, P, P, P],
     "adm_conv_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_f32_to_bf16": [P, P, L, P],
@@ -59,7 +62,7 @@ _SIGS = {
     "adm_add": [P, P, P, L, P],
     "adm_copy_channels": [P, I, I, P, I, I, L, I, F, I, P],
     "adm_spatial_att_fwd": [P, I, P, P, P, P, I, I, I, P],
-    "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, I, I, I, P],
+    "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, P, I, I, I, P],
     "adm_q_sample": [P, P, P, P, I, L, I, P],
     "adm_ddm_loss": [P, P, P, P, P, P, P, P, F, I, L, P],
     "adm_ddm_loss_latent": [P, P, P, P, P, P, P, P, P, P, P, F, I, L, P],
@@ -67,7 +70,8 @@ _SIGS = {
     "adm_sampler_step_stochastic": [P, P, P, P, P, P, I, I, D, I, I, L, P],
     "adm_aug_workspace_floats": [I, I, I, I],
     "adm_augment_geometric": [P, P, P, P, P, P, I, I, I, I, P],
-    "adm_sumsq": [P, P, L, P],
+    "adm_sumsq_blocks": [L],
+    "adm_sumsq": [P, P, P, L, P],
     "adm_adamw_step": [P, P, P, P, P, P, L, F, F, F, F, F, F, I, F, F, P],
 }
 EXPORTS = tuple(_SIGS)
@@ -103,6 +107,10 @@ def stream() -> c_void_p:
 
 def ptr(t) -> c_void_p:
     return None if t is None else c_void_p(t.data_ptr())
+
+
+NO_STREAM = ("adm_version", "adm_conv_splitk", "adm_gn_splits", "adm_aug_workspace_floats", "adm_conv_wgrad_plan",
+             "adm_sumsq_blocks")      # host-side queries: no stream argument, called as lib().name(...)
 
 
 def call(name: str, *args):

@@ -74,6 +74,12 @@ COMPUTE = "f32"
 WINOGRAD = os.environ.get("ADM_WINOGRAD", "1") != "0"
 WINO_MIN_M = 8192
 
+# ADM_DETERMINISTIC=1: bitwise reproducible backward.  The weight / bias gradient kernels normally combine their pixel-range
+# splits with fp32 atomics (order-dependent rounding); with this switch every split stores its partial tile to a workspace
+# and the unpack launch sums them in split order (adm_conv_wgrad_ws / adm_unpack_wgrad_splits).  Everything else on the
+# training step (forward, data gradients, GroupNorm, attention, loss, norm, optimiser) is reproducible unconditionally.
+DETERMINISTIC = os.environ.get("ADM_DETERMINISTIC", "0") == "1"
+
 
 def set_compute_precision(mode: str):
     global COMPUTE
@@ -336,7 +342,6 @@ class _Conv(torch.autograd.Function):
             nonlocal dw, db
             fused_b = False
             if ctx.needs_input_grad[1]:
-                dwp = _new((cop, ks * ks * cip), dy)
                 # fp32: the weight-gradient kernel also produces the bias gradient (column sums of dy) on its way
                 dbp = None
                 if need_b and not bf16:
@@ -351,16 +356,39 @@ class _Conv(torch.autograd.Function):
                         dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
                 wino_w = (not bf16 and _use_wino(B, Ho, Wo, ks, up, -1) and not qkv and pow2(Ho) and pow2(Wo))
+                det = DETERMINISTIC and not bf16
+                splits = 1
+                if det:        # splits store partial tiles to a workspace; the unpack launch sums them in a fixed order
+                    splits = hip.lib().adm_conv_wgrad_plan(B, Ho, Wo, cip, cop, ks, int(up), int(wino_w))
+                    if splits < 1:
+                        raise RuntimeError(f"adm_conv_wgrad_plan failed with code {splits}")
+                    dwp = _new((splits, cop, ks * ks * cip), dy)
+                    bws = _new((splits, cop), dy) if dbp is not None else None
+                else:
+                    dwp = _new((cop, ks * ks * cip), dy)
                 with _Prof("wgrad_wino" if wino_w else "wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"wgrad{'-wino' if wino_w else ''} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16:
                         call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+                    elif det:
+                        call("adm_conv_wgrad_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, ks, int(up),
+                             splits, int(wino_w))
                     elif wino_w:
                         call("adm_conv_wgrad_wino_up" if up else "adm_conv_wgrad_wino", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B,
                              Ho, Wo, cip, cip, cop, cop, 0)
                     else:
                         call("adm_conv_wgrad_bias", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, ks,
                              int(up), 0)
+                if wsink is not None:
+                    dst, acc = wsink, 1
+                else:
+                    dw = torch.empty_like(weight)
+                    dst, acc = dw, 0
+                if det:
+                    call("adm_unpack_wgrad_splits", ptr(dwp), splits, ptr(dst), co, ci, ks, cop, cip, int(qkv), acc, ptr(bws),
+                         ptr(dbp))
+                else:
+                    call("adm_unpack_wgrad", ptr(dwp), ptr(dst), co, ci, ks, cop, cip, int(qkv), acc)
                 if fused_b:
                     if not qkv and cop == co:
                         if bsink is not None:
@@ -369,11 +397,7 @@ class _Conv(torch.autograd.Function):
                         db = _new((co,), dy)
                         call("adm_permute_vec", ptr(dbp), ptr(db), co, co, int(qkv), 1)
                 if wsink is not None:
-                    call("adm_unpack_wgrad", ptr(dwp), ptr(wsink), co, ci, ks, cop, cip, int(qkv), 1)
                     _notify(weight)
-                else:
-                    dw = torch.empty_like(weight)
-                    call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, int(qkv), 0)
             if need_b and not fused_b:
                 if not qkv and cop == co:
                     if bsink is not None:
@@ -660,8 +684,9 @@ class _SpatialAtt(torch.autograd.Function):
         dh = torch.empty_like(h)
         datt = torch.empty_like(att)
         dqk = torch.zeros_like(qk)
-        call("adm_spatial_att_bwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(dy), ptr(dh), ptr(datt), ptr(dqk), B,
-             H * W, C)
+        part = _new((B, 4), h)           # per-image partials, summed in image order (no atomics: reproducible)
+        call("adm_spatial_att_bwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(dy), ptr(dh), ptr(datt), ptr(dqk), ptr(part),
+             B, H * W, C)
         return datt, dqk, dh, dy
 
 

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import ops
+from . import hip, ops
 from .hip import call, ptr
 
 
@@ -159,6 +159,8 @@ class FusedAdamWEMA:
         self.v = torch.zeros_like(flat.flat)
         self.ema = flat.flat.clone() if ema else None
         self.sumsq = torch.zeros(1, device=flat.flat.device, dtype=torch.float64)
+        # per-workgroup partials of the gradient norm, combined in a fixed order: the clip factor is bitwise reproducible
+        self.partials = torch.zeros(hip.lib().adm_sumsq_blocks(flat.numel), device=flat.flat.device, dtype=torch.float64)
         self.step_count = 0
 
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0, ema_decay: Optional[float] = None):
@@ -168,7 +170,7 @@ class FusedAdamWEMA:
         ops.join_side_streams()        # weight gradients are produced on a side stream (ops.SIDE_WGRAD)
         self.step_count += 1
         self.sumsq.zero_()
-        call("adm_sumsq", ptr(f.grad), ptr(self.sumsq), f.numel)
+        call("adm_sumsq", ptr(f.grad), ptr(self.sumsq), ptr(self.partials), f.numel)
         ema_ptr = ptr(self.ema) if (self.ema is not None and ema_decay is not None) else None
         call("adm_adamw_step", ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), ema_ptr, ptr(self.sumsq), f.numel,
              float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),

@@ -93,6 +93,15 @@ int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbia
 int adm_conv_wgrad_wino_up(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx,
                            int Cout, int lddy, int splits, hipStream_t stream);
 
+/* Deterministic weight gradients (bitwise reproducible backward; SURVEY.md section 5.2 "run twice, bit-compare").  The
+ * kernels above combine their pixel-range splits with fp32 atomics.  Here split z writes its partial tile with plain stores
+ * to ws[z][Cout][ks*ks][Cin] (and its bias partial to bws[z][Cout], bws may be NULL) and adm_unpack_wgrad_splits sums the
+ * splits in a fixed order.  adm_conv_wgrad_plan returns the split count the launcher picks (>= 1) for the direct
+ * (wino = 0) or Winograd F(3,2) (wino = 1: ks = 3, power-of-two H and W) kernel; pass it as `splits`. */
+int adm_conv_wgrad_plan(int B, int H, int W, int Cin, int Cout, int ks, int up, int wino);
+int adm_conv_wgrad_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
+                      int lddy, int ks, int up, int splits, int wino, hipStream_t stream);
+
 /* ---- reduced-precision option (BASELINE.json configs[2], "bf16"): same contracts as adm_conv_fwd / adm_conv_wgrad,
  * tensors stay fp32 in HBM, the contraction runs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 on their way
  * into LDS, fp32 accumulation).  wp16 = the adm_pack_weight layouts converted with adm_f32_to_bf16.  Cin % 64 == 0
@@ -120,6 +129,10 @@ int adm_pack_weight_table(const long* table, int n_entries, long total_tiles, hi
 /* inverse of the fwd packing for gradients: dw OIHW = (accumulate ? dw : 0) + dwp */
 int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
                      int accumulate, hipStream_t stream);
+/* adm_unpack_wgrad over the `splits` partial gradients of adm_conv_wgrad_ws, summed in split order; bias partials
+ * bws[splits][Co_pad] are summed into dbias[0..Co_pad) (+=, packed channel order); bws and dbias may both be NULL. */
+int adm_unpack_wgrad_splits(const float* ws, int splits, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
+                            int accumulate, const float* bws, float* dbias, hipStream_t stream);
 /* out[i] = in[perm(i)] over n_pad entries (zero beyond n); qkv permutation of bias vectors.
  * inverse=1 maps packed order back to the reference order. */
 int adm_permute_vec(const float* in, float* out, int n, int n_pad, int qkv, int inverse, hipStream_t stream);
@@ -221,9 +234,10 @@ int adm_axpby_b(const void* x, int x_is_f64, const float* y, const float* a, con
  * q = qw*att+qb, k = kw*att+kb; qk = {qw,qb,kw,kb} on device.  HW <= 64. */
 int adm_spatial_att_fwd(const float* att, int ldatt, const float* qk, const float* h, const float* xres, float* y,
                         int B, int HW, int C, hipStream_t stream);
-/* dh, datt (channel 0 of [B][HW][ldatt], other channels zeroed), dqk[4] (accumulated) */
+/* dh, datt (channel 0 of [B][HW][ldatt], other channels zeroed), dqk[4] (accumulated).  dqk_part = [B][4] workspace:
+ * per-image partials summed in image order (deterministic); NULL = fp32 atomics. */
 int adm_spatial_att_bwd(const float* att, int ldatt, const float* qk, const float* h, const float* dy, float* dh,
-                        float* datt, float* dqk, int B, int HW, int C, hipStream_t stream);
+                        float* datt, float* dqk, float* dqk_part, int B, int HW, int C, hipStream_t stream);
 
 /* ---------------- analytic schedule (ddm/ddm_const.py, ddm/ddm_const_2.py) -------------------- */
 
@@ -268,8 +282,11 @@ int adm_augment_geometric(const float* images, const int* flips, const int* marg
 
 /* ---------------- optimiser (train_uncond_dpm.py:292-310, ddm/ema.py:158-188) ---------------- */
 
-/* sumsq[0] += sum g^2 */
-int adm_sumsq(const float* g, double* sumsq, long n, hipStream_t stream);
+/* sumsq[0] += sum g^2.  partials = workspace of adm_sumsq_blocks(n) doubles: per-workgroup partial sums combined in a
+ * fixed order by a second launch (the norm, hence the clip factor and the update, are bitwise reproducible); NULL = one
+ * launch with fp64 atomics. */
+int adm_sumsq_blocks(long n);
+int adm_sumsq(const float* g, double* sumsq, double* partials, long n, hipStream_t stream);
 /* AdamW step on flat buffers with the clip factor computed on device from sumsq[0]:
  * g *= min(1, max_norm/(sqrt(sumsq)+1e-6)); decoupled weight decay; optional EMA lerp
  * (ema += (1-decay)(p-ema)) fused into the same pass when ema != NULL. */

@@ -195,9 +195,33 @@ class Trainer:
             self.model.scale_factor = data["model"]["scale_factor"].to(self.device)
         self.model.load_state_dict(data["model"])
         self.step = data["step"]
-        if isinstance(data.get("opt"), dict) and "exp_avg" in data["opt"]:
-            self.opt.m.copy_(data["opt"]["exp_avg"]); self.opt.v.copy_(data["opt"]["exp_avg_sq"])
-            self.opt.step_count = int(data["opt"]["step"])
+        opt = data.get("opt")
+        if isinstance(opt, dict) and "exp_avg" in opt:                   # this build's flat layout
+            self.opt.m.copy_(opt["exp_avg"]); self.opt.v.copy_(opt["exp_avg_sq"])
+            self.opt.step_count = int(opt["step"])
+        elif isinstance(opt, dict) and "state" in opt and "param_groups" in opt:
+            # torch.optim.AdamW.state_dict() as the reference's Trainer.save writes it (train_uncond_dpm.py:178-179, 214):
+            # per-parameter {'step','exp_avg','exp_avg_sq'} indexed in the order of filter(requires_grad, model.parameters()),
+            # which is the order of the flat buffers
+            state = opt["state"]
+            if len(state) not in (0, len(self.flat.params)):
+                raise RuntimeError(f"checkpoint optimiser state has {len(state)} parameters, the model {len(self.flat.params)}")
+            steps = set()
+            for idx, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+                st = state.get(idx)
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise RuntimeError(f"optimiser state {idx}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+                self.opt.m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                self.opt.v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            if len(steps) > 1:
+                raise RuntimeError(f"per-parameter optimiser step counts differ ({sorted(steps)}): not representable in the fused step")
+            if steps:
+                self.opt.step_count = steps.pop()
+        elif opt is not None:
+            raise RuntimeError("checkpoint 'opt' entry has an unknown layout")
         if self.rank == 0 and "ema" in data:
             names = [n for n, p in self.model.named_parameters() if p.requires_grad]
             for n, p, o in zip(names, self.flat.params, self.flat.offsets):
