@@ -474,7 +474,7 @@ class _GroupNormAct(torch.autograd.Function):
         S = hip.lib().adm_gn_splits(HW, C)
         stats = _new((B, G, 2), x)
         ws = _new((B * S * G * 2,), x, torch.float64)
-        prof = _Prof("gn", 12.0 * x.numel(), f"gn-fwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)")
+        prof = _Prof("gn", 8.0 * x.numel(), f"gn-fwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)")
         prof.__enter__()
         ssc, bstride = None, 0
         if ss is not None:
@@ -513,7 +513,7 @@ class _GroupNormAct(torch.autograd.Function):
         dgamma = sg if direct else torch.zeros_like(gamma)
         dbeta = sb if direct else torch.zeros_like(beta)
         red = _new((B * S * C * 2 + B * C * 2 + B * G * 2,), x)
-        with _Prof("gn", 20.0 * x.numel(), f"gn-bwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)"):
+        with _Prof("gn", (12.0 if add is None else 16.0) * x.numel(), f"gn-bwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)"):
             call("adm_gn_bwd_add", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
                  ptr(add), ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
         if direct:

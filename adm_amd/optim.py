@@ -14,6 +14,7 @@ no packing, and the optimiser is a single launch over 216 M elements.
 """
 from __future__ import annotations
 
+import time
 from typing import List, Optional
 
 import torch
@@ -93,6 +94,8 @@ class BucketedGradReducer:
         self.seen = [False] * len(flat.params)
         self.enabled = True
         self.handles = []
+        self.exposed_ms, self.finishes = 0.0, 0     # diagnostics: time finish() waited for the all-reduces (bench.py "dist")
+        self.measure = False
         if self.active:
             for idx, p in enumerate(flat.params):
                 hook = self._make_hook(idx)
@@ -139,10 +142,19 @@ class BucketedGradReducer:
             for b in range(len(self.buckets)):
                 if self.pending[b] != self.buckets[b][2]:
                     self._launch(b)
+            t0 = None
+            if self.measure and self.cuda:
+                # exposed communication: drain the compute stream first, then time how long the collectives still need
+                torch.cuda.current_stream().synchronize()
+                t0 = time.perf_counter()
             for h in self.handles:
                 h.wait()
             if self.side is not None:
                 torch.cuda.current_stream().wait_stream(self.side)
+            if t0 is not None:
+                torch.cuda.current_stream().synchronize()
+                self.exposed_ms += (time.perf_counter() - t0) * 1e3
+                self.finishes += 1
         self.handles = []
         self.pending = [0] * len(self.buckets)
         self.seen = [False] * len(self.flat.params)

@@ -236,6 +236,12 @@ def main():
         ops.PROFILE = []
     train_step(args.warmup + args.steps)
     barrier()
+    if reducer.active:        # two more untimed steps that measure how much of the all-reduce is NOT hidden under backward
+        reducer.measure = True
+        for i in range(2):
+            train_step(args.warmup + args.steps + 1 + i)
+        barrier()
+        reducer.measure = False
     if rank == 0:
         recs, ops.PROFILE = ops.PROFILE, None
         log(f"profiled step: {len(recs)} GEMM-shaped launches")
@@ -251,73 +257,80 @@ def main():
             for tag, (f_, m_, n_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 log(f"  {tag:44s} n={n_:3d} total={m_:8.2f} ms  {f_ / max(m_, 1e-9) / 1e9:7.1f} TFLOP/s")
         # Dominant kernel: the Winograd F(2,3) 3x3-conv kernel when it ran (fp32), else the direct implicit GEMM.
-        # `achieved` counts ALGORITHMIC flops = the direct convolution's 2*M*N*9*Cin (SURVEY 8d's per-image figures);
-        # Winograd executes 2/3 of them, so `executed` (what the MFMA pipe really did) is what `peak` physically bounds and
-        # `frac` = achieved / peak can exceed the MFMA-busy fraction.
+        # Convention of every entry below: `achieved` / `frac` count the flops the MFMA pipe EXECUTED -- the
+        # Winograd kernels execute 2/3 of the direct convolution's 2*M*N*9*Cin -- so frac = achieved / peak is a true roofline
+        # fraction (<= 1) and is comparable with the PMC MFMA-busy fraction; the ALGORITHMIC (direct-convolution) rate, which
+        # is what images/s follow, is carried beside it as `algorithmic` / `algorithmic_over_peak` (may exceed 1).
         wino = by.get("wino")
         dom_kind = "wino" if wino and wino[1] > by.get("igemm", [0, 0, 0])[1] else "igemm"
-        fl, ms, n = by.get(dom_kind, [0.0, 1e-9, 0])
         # HBM-side traffic per launch comes from rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
         # WRITE_SIZE runs, FETCH doubled per MI355X_MICROARCH.md): counters cannot be read from inside the process.
-        traffic, traffic_src, pmc_all = None, None, {}
+        traffic_src, pmc_all = None, {}
         try:
             pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))[-1]
             pmc_all = json.load(open(os.path.join(ROOT, "profiles", pmc)))
-            traffic = pmc_all.get(dom_kind, {}).get("traffic_bytes_per_launch")
             traffic_src = "profiles/" + pmc
         except Exception:
             pass
         if args.dtype != "f32" or args.config != "cifar":
-            pmc_all, traffic, traffic_src = {}, None, None    # the committed PMC passes are of the fp32 CIFAR run
+            pmc_all, traffic_src = {}, None    # the committed PMC passes are of the fp32 CIFAR run
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        kname = {"wino": "igemm_wino_kernel (3x3 conv forward + data-gradient, Winograd F(2,3), fp32 MFMA)",
-                 "igemm": ("igemm_f32_kernel" if args.dtype == "f32" else "igemm_bf16_kernel") + " (conv/linear forward + data-gradient)"}[dom_kind]
-        exec_factor = (2.0 / 3.0) if dom_kind == "wino" else 1.0
-        roof = {"kernel": kname, "bound": "mfma",
-                "achieved": round(fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(fl / ms / 1e9 / peak, 4), "traffic": traffic,
-                "traffic_unit": "bytes/launch (L2-miss side: HBM + Infinity Cache)", "traffic_source": traffic_src,
-                "algorithmic_flops_per_launch": round(fl / max(n, 1)), "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "ms_per_step_in_kernel": round(ms, 2),
-                "executed": round(fl * exec_factor / ms / 1e9, 2), "frac_executed": round(fl * exec_factor / ms / 1e9 / peak, 4),
-                "note": "achieved = algorithmic (direct-convolution) flops / time; Winograd F(2,3) executes 2/3 of them: "
-                        "executed / frac_executed are what the MFMA pipe did" if dom_kind == "wino" else None,
-                "mfma_busy_pmc": pmc_all.get(dom_kind, {}).get("mfma_busy_fraction"),
-                "sustained_clock_GHz_pmc": pmc_all.get(dom_kind, {}).get("effective_clock_GHz")}
-        if dom_kind == "wino" and "igemm" in by:
-            fl1, ms1, n1 = by["igemm"]
-            roof["igemm_direct"] = {"kernel": "igemm_f32_kernel (1x1 / Linear / small-map / fused-upsample convs)",
-                                    "achieved": round(fl1 / ms1 / 1e9, 2), "frac": round(fl1 / ms1 / 1e9 / peak, 4),
-                                    "launches_per_step": n1, "ms_per_step_in_kernel": round(ms1, 2),
-                                    "mfma_busy_pmc": pmc_all.get("igemm", {}).get("mfma_busy_fraction")}
-        if "wgrad_wino" in by:
-            fl4, ms4, n4 = by["wgrad_wino"]
-            roof["wgrad_wino"] = {"kernel": "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3,2))",
-                                  "achieved": round(fl4 / ms4 / 1e9, 2), "frac": round(fl4 / ms4 / 1e9 / peak, 4),
-                                  "executed": round(fl4 * 2 / 3 / ms4 / 1e9, 2), "frac_executed": round(fl4 * 2 / 3 / ms4 / 1e9 / peak, 4),
-                                  "launches_per_step": n4, "ms_per_step_in_kernel": round(ms4, 2),
-                                  "mfma_busy_pmc": pmc_all.get("wgrad_wino", {}).get("mfma_busy_fraction")}
-        if "wgrad" in by:
-            fl2, ms2, n2 = by["wgrad"]
-            roof["wgrad"] = {"kernel": "wgrad_f32_kernel (direct: 1x1 / Linear / small-map / fused-upsample layers)", "achieved": round(fl2 / ms2 / 1e9, 2),
-                             "frac": round(fl2 / ms2 / 1e9 / peak, 4), "launches_per_step": n2,
-                             "ms_per_step_in_kernel": round(ms2, 2),
-                             "mfma_busy_pmc": pmc_all.get("wgrad", {}).get("mfma_busy_fraction")}
+        EXEC = {"wino": 2.0 / 3.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
+        NAMES = {"wino": "igemm_wino_kernel (3x3 conv forward + data-gradient, Winograd F(2,3), fp32 MFMA)",
+                 "igemm": ("igemm_f32_kernel" if args.dtype == "f32" else "igemm_bf16_kernel") +
+                          " (1x1 / Linear / small-map / fused-upsample convs: forward + data-gradient)",
+                 "wgrad_wino": "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3,2))",
+                 "wgrad": "wgrad_f32_kernel (direct: 1x1 / Linear / small-map layers)",
+                 "attn": "attn_fwd / attn_bwd_dq / attn_bwd_dkv"}
+
+        def mfma_entry(kind):
+            fl, ms, n = by[kind]
+            ex = EXEC[kind]
+            e = {"kernel": NAMES[kind], "bound": "mfma", "achieved": round(fl * ex / ms / 1e9, 2), "peak": peak,
+                 "unit": "TFLOP/s", "frac": round(fl * ex / ms / 1e9 / peak, 4),
+                 "algorithmic": round(fl / ms / 1e9, 2), "algorithmic_over_peak": round(fl / ms / 1e9 / peak, 4),
+                 "executed_over_algorithmic_flops": round(ex, 4),
+                 "algorithmic_flops_per_launch": round(fl / max(n, 1)), "launches_per_step": n,
+                 "avg_launch_ms": round(ms / max(n, 1), 4), "ms_per_step_in_kernel": round(ms, 2),
+                 "traffic": pmc_all.get(kind, {}).get("traffic_bytes_per_launch"),
+                 "mfma_busy_pmc": pmc_all.get(kind, {}).get("mfma_busy_fraction"),
+                 "sustained_clock_GHz_pmc": pmc_all.get(kind, {}).get("effective_clock_GHz")}
+            if kind == "attn":
+                e["note"] = ("algorithmic flops: 4 L^2 d forward, 10 L^2 d backward per (image, head); the backward EXECUTES "
+                             "7 products for these 5, which mfma_busy_pmc sees and `achieved` does not count")
+            return e
+
+        roof = mfma_entry(dom_kind)
+        roof.update({"traffic_unit": "bytes/launch (L2-miss side: HBM + Infinity Cache), rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE",
+                     "traffic_source": traffic_src,
+                     "note": "achieved = EXECUTED MFMA flops / kernel time (HIP events around every launch of one profiled step); "
+                             "frac = achieved / peak.  Winograd F(2,3) executes 2/3 of the direct convolution's flops: "
+                             "`algorithmic` is the direct-convolution rate (SURVEY 8d's 213.9 GFLOP/image figures)."})
+        for kind, key in (("igemm", "igemm_direct"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
+            if kind in by and kind != dom_kind:
+                roof[key] = mfma_entry(kind)
+        # whole step against the MFMA roof: every GEMM-shaped launch of the profiled step
+        alg = sum(by[k][0] for k in EXEC if k in by)
+        exe = sum(by[k][0] * EXEC[k] for k in EXEC if k in by)
+        roof["step"] = {"algorithmic_tflop": round(alg / 1e12, 3), "executed_tflop": round(exe / 1e12, 3),
+                        "ms_per_step": round(ms_per_step, 2),
+                        "algorithmic_tflops": round(alg / ms_per_step / 1e9, 2), "executed_tflops": round(exe / ms_per_step / 1e9, 2),
+                        "frac": round(exe / ms_per_step / 1e9 / peak, 4),
+                        "ms_in_mfma_kernels": round(sum(by[k][1] for k in EXEC if k in by), 2),
+                        "note": "executed MFMA flops of ALL GEMM-shaped kernels / wall time of a whole optimiser step / peak"}
         if "gn" in by:      # the HBM-bound part of the ResBlock: GroupNorm + scale/shift + SiLU + dropout, forward and backward
-            by3, ms5, n5 = by["gn"]                 # `flops` slot carries algorithmic bytes (12 B/elem fwd, 20 B/elem bwd)
-            roof["groupnorm"] = {"kernel": "gn_* (GroupNorm+SiLU+dropout fwd/bwd)", "bound": "hbm",
+            by3, ms5, n5 = by["gn"]        # `flops` slot carries MINIMAL bytes: 8 B/elem fwd (read x, write y), 12 bwd (x, dy, dx) (+4 residual)
+            gn_traffic = pmc_all.get("gn", {}).get("traffic_bytes_per_launch")
+            gn_launches = pmc_all.get("gn", {}).get("launches_in_pmc_run")
+            roof["groupnorm"] = {"kernel": "gn_* (GroupNorm+scale/shift+SiLU+dropout fwd/bwd)", "bound": "hbm",
                                  "achieved": round(by3 / ms5 / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                  "frac": round(by3 / ms5 / 1e6 / 8000.0, 4), "calls_per_step": n5,
-                                 "ms_per_step_in_kernel": round(ms5, 2),
-                                 "note": "algorithmic bytes of the multi-pass formulation (x read twice + y written; x, dy read "
-                                         "twice + dx written); the register-resident small-map kernels move fewer"}
-        if "attn" in by:
-            fl3, ms3, n3 = by["attn"]
-            roof["attention"] = {"kernel": "attn_fwd/bwd kernels", "achieved": round(fl3 / ms3 / 1e9, 2),
-                                 "frac": round(fl3 / ms3 / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": n3,
-                                 "ms_per_step_in_kernel": round(ms3, 2),
-                                 "mfma_busy_pmc": pmc_all.get("attn", {}).get("mfma_busy_fraction"),
-                                 "note": "achieved/frac count ALGORITHMIC flops (the backward executes 7 products for 5); "
-                                         "mfma_busy_pmc is SQ_VALU_MFMA_BUSY_CYCLES over all SIMDs from the committed PMC pass"}
+                                 "minimal_bytes_per_step": round(by3), "ms_per_step_in_kernel": round(ms5, 2),
+                                 "traffic": gn_traffic, "traffic_launches_in_pmc_run": gn_launches,
+                                 "note": "achieved = MINIMAL bytes (x read once + y written = 8 B/element forward; x, dy read + dx "
+                                         "written = 12 B/element backward, +4 where the residual gradient is added in the same "
+                                         "pass) / time.  The multi-pass kernels read x (and dy) twice on the large maps: "
+                                         "`traffic` is the PMC bytes per kernel launch (several launches per call)"}
     # ---- 10-step sampling, every rank samples its own batch, no collectives ----
     if not args.no_sample:
         dpm.eval()
@@ -355,7 +368,13 @@ def main():
                                       ", clip 1.0 + AdamW + EMA(every 8)" + (", use_augment (AugmentPipe p=0.15 + labels)" if args.augment else ""),
                           "global_batch": world * B, "image": f"3x{R}x{R}", "sampling_timesteps": 10,
                           "parallelism": f"dp{world}", "valid": not args.small},
-               "final_loss": round(final_loss, 4), "roofline": roof}
+               "final_loss": round(final_loss, 4), "roofline": roof,
+               "dist": {"backend": (dist.get_backend() if use_dist else None),
+                        "nranks": (dist.get_world_size() if use_dist else 1),
+                        "reducer_active": reducer.active, "buckets": len(reducer.buckets), "bucket_MiB": 64,
+                        "allreduce_exposed_ms_per_step": round(reducer.exposed_ms / max(1, reducer.finishes), 3),
+                        "note": "exposed = host-measured time finish() spent waiting for the all-reduce side stream after the "
+                                "backward's own kernels had drained (0 when the reducer is inactive)"}}
         if not args.no_cpu_baseline and world == 1 and args.config == "cifar":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

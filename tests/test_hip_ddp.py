@@ -150,3 +150,27 @@ def test_trainer_two_ranks_checkpoint(tmp_path):
     ck = torch.load(os.path.join(res, "model-1.pt"), map_location="cpu", weights_only=True)
     assert ck["step"] == 2 and "ema_model.model.model.enc.32x32_conv.weight" in ck["ema"]
     assert os.path.exists(os.path.join(res, "sample-1.png"))
+
+
+def test_bench_runs_over_a_one_rank_rccl_communicator():
+    """The REAL backend on the driver's one-GPU box: `bench.py --small` with ADM_FORCE_DIST=1 builds a 1-rank `nccl`
+    (= RCCL) process group, so the hooks, the side stream, the bucketed ncclAllReduce calls and the exposed-wait diagnostic
+    all run on hardware; the JSON line must say which backend and how many ranks RCCL saw."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "3", "--warmup", "1", "--batch", "16",
+                        "--no-cpu-baseline", "--no-sample"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    d = out["dist"]
+    assert d["backend"] == "nccl" and d["nranks"] == 1 and d["reducer_active"] is True and d["buckets"] >= 1
+    assert d["allreduce_exposed_ms_per_step"] >= 0.0
+    assert out["value"] > 0 and out["config"]["valid"] is False       # --small is a debug configuration
+    assert 0 < out["roofline"]["frac"] <= 1.0 and 0 < out["roofline"]["step"]["frac"] <= 1.0
