@@ -180,6 +180,9 @@ class DhariwalUNet(nn.Module):
             raise NotImplementedError("class-conditional labels are not on the DDM hot path")
         if out_mul != 1:
             raise NotImplementedError("out_mul != 1 (ddm_linear) is out of scope")
+        if any((model_channels * m) % 32 for m in channel_mult):
+            raise NotImplementedError("channel widths must be multiples of 32 (the HIP GEMM operands' channel granularity); "
+                                      f"got model_channels={model_channels}, channel_mult={list(channel_mult)}")
         self.variant = variant
         self.two_decoders = variant in ("uncond_unet", "uncond_unet_2")
         self.label_dropout = label_dropout

@@ -14,7 +14,7 @@ from parity import close
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CKPT = os.path.join(ROOT, "tests", "golden", "ref_checkpoint_model-1.pt")
-UNET_KW = dict(img_resolution=16, img_channels=3, model_type="DhariwalUNet", model_channels=16, channel_mult=[1, 2],
+UNET_KW = dict(img_resolution=16, img_channels=3, model_type="DhariwalUNet", model_channels=32, channel_mult=[1],
                channel_mult_emb=2, num_blocks=1, attn_resolutions=[8], dropout=0.0, augment_dim=0)
 MODEL_CFG = dict(eps=1e-3, sigma_max=1, sigma_min=0.001, weighting_loss=True, use_augment=False)
 

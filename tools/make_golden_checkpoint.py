@@ -37,9 +37,9 @@ import ddm.ddm_const_2 as D2  # noqa: E402
 from ddm.ema import EMA  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-# 16/32 channels: below the 64 channels per head of the Dhariwal blocks, so the fixture has no attention layers (the file
+# 32 channels (a multiple of 32, the HIP path's channel granularity; below the 64 channels per head of the Dhariwal blocks, so the fixture has no attention layers (the file
 # holds five copies of the weights -- model, EMA online + shadow, two AdamW moments -- and must stay small)
-UNET_KW = dict(img_resolution=16, img_channels=3, model_type="DhariwalUNet", model_channels=16, channel_mult=[1, 2],
+UNET_KW = dict(img_resolution=16, img_channels=3, model_type="DhariwalUNet", model_channels=32, channel_mult=[1],
                channel_mult_emb=2, num_blocks=1, attn_resolutions=[8], dropout=0.0, augment_dim=0)
 MODEL_CFG = dict(eps=1e-3, sigma_max=1, sigma_min=0.001, weighting_loss=True, use_augment=False)
 
