@@ -1,0 +1,397 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the conditional super-resolution denoiser of SURVEY.md section 8(f) rank 4 /
+BASELINE configs[4]: a functional plain-PyTorch restatement of /root/reference/unet/cond_unet_sd.py (`Unet`, single decoder)
+and of /root/reference/unet/cond_unet.py (the two-decoder variant the DIV2K YAML names,
+configs/super-resolution/div2k_cond_ddm_const_ldm.yaml:42), driven by a state_dict with the reference's own key names.
+
+Only tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg and tools/make_golden_cond.py may import this module.
+Pinned: tools/make_golden_cond.py imports the REAL reference module (import-time stubs for torchvision / fvcore only, see
+that script) and checks every function here against it (tests/golden/oracle_vs_reference_report_cond.json).
+
+The condition ENCODER (`init_conv_mask`: torchvision Swin-B, cond_unet_sd.py:637-650) is NOT restated: its torchvision ops
+are absent offline and its pretrained weights unfetchable.  Its four feature maps hm[0..3] (f, 2f, 4f, 8f channels at 1/4,
+1/8, 1/16, 1/32 of the condition image; f = 128 for Swin-B) are INPUTS here ("parity unpinned" for the encoder itself).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------ small layers
+def gaussian_fourier(W, x):
+    """GaussianFourierProjection (cond_unet_sd.py:396-405): cat[sin, cos](x W 2 pi)."""
+    p = x[:, None] * W[None, :] * 2 * math.pi
+    return torch.cat([torch.sin(p), torch.cos(p)], dim=-1)
+
+
+def time_mlp(sd, c_noise):
+    """time_mlp = fourier -> Linear -> GELU -> Linear (cond_unet_sd.py:696-701)."""
+    h = gaussian_fourier(sd["time_mlp.0.W"], c_noise)
+    h = F.linear(h, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
+    return F.linear(F.gelu(h), sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
+
+
+def ws_weight(w, eps=1e-5):
+    """WeightStandardizedConv2d (cond_unet_sd.py:344-357): per out-channel (w - mean) * rsqrt(var_biased + eps)."""
+    m = w.mean(dim=(1, 2, 3), keepdim=True)
+    v = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    return (w - m) * torch.rsqrt(v + eps)
+
+
+def layer_norm_c(x, g, eps=1e-5):
+    """LayerNorm over channels per pixel with gain g, no bias (cond_unet_sd.py:359-368)."""
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    mean = x.mean(dim=1, keepdim=True)
+    return (x - mean) * torch.rsqrt(var + eps) * g
+
+
+def block(sd, p, x, scale_shift=None, groups=8):
+    """Block (cond_unet_sd.py:426-442): WS conv3x3 -> GroupNorm(groups) -> x (scale + 1) + shift -> SiLU."""
+    x = F.conv2d(x, ws_weight(sd[p + ".proj.weight"]), sd[p + ".proj.bias"], padding=1)
+    x = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-5)
+    if scale_shift is not None:
+        scale, shift = scale_shift
+        x = x * (scale + 1) + shift
+    return F.silu(x)
+
+
+def resnet_block(sd, p, x, t_emb, groups=8):
+    """ResnetBlock (cond_unet_sd.py:444-468)."""
+    te = F.linear(F.silu(t_emb), sd[p + ".mlp.1.weight"], sd[p + ".mlp.1.bias"])[:, :, None, None]
+    ss = te.chunk(2, dim=1)
+    h = block(sd, p + ".block1", x, ss, groups)
+    h = block(sd, p + ".block2", h, None, groups)
+    if p + ".res_conv.weight" in sd:
+        x = F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
+    return h + x
+
+
+def linear_attention(sd, p, x, heads=4, dim_head=32):
+    """Residual(PreNorm(LinearAttention)) (cond_unet_sd.py:502-530, 327-333, 370-378); p = '<...>.fn'."""
+    b, c, h, w = x.shape
+    xn = layer_norm_c(x, sd[p + ".norm.g"])
+    qkv = F.conv2d(xn, sd[p + ".fn.to_qkv.weight"]).chunk(3, dim=1)
+    q, k, v = [t.reshape(b, heads, dim_head, h * w) for t in qkv]
+    q = q.softmax(dim=-2) * dim_head ** -0.5
+    k = k.softmax(dim=-1)
+    v = v / (h * w)
+    context = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", context, q).reshape(b, heads * dim_head, h, w)
+    out = F.conv2d(out, sd[p + ".fn.to_out.0.weight"], sd[p + ".fn.to_out.0.bias"])
+    return layer_norm_c(out, sd[p + ".fn.to_out.1.g"]) + x
+
+
+def full_attention(sd, p, x, heads=4, dim_head=32):
+    """Residual(PreNorm(Attention)) of the middle (cond_unet_sd.py:532-554)."""
+    b, c, h, w = x.shape
+    xn = layer_norm_c(x, sd[p + ".norm.g"])
+    qkv = F.conv2d(xn, sd[p + ".fn.to_qkv.weight"]).chunk(3, dim=1)
+    q, k, v = [t.reshape(b, heads, dim_head, h * w) for t in qkv]
+    sim = torch.einsum("bhdi,bhdj->bhij", q * dim_head ** -0.5, k)
+    out = torch.einsum("bhij,bhdj->bhid", sim.softmax(dim=-1), v)
+    out = out.permute(0, 1, 3, 2).reshape(b, heads * dim_head, h, w)
+    return F.conv2d(out, sd[p + ".fn.to_out.weight"], sd[p + ".fn.to_out.bias"]) + x
+
+
+def spatial_att(sd, p, x):
+    """SpatialAtt (cond_unet_sd.py:112-130): 1-channel HW x HW softmax gate, softsign(att) * x."""
+    b, _, h, w = x.shape
+    att = F.conv2d(x, sd[p + ".map.weight"], sd[p + ".map.bias"])
+    q = F.conv2d(att, sd[p + ".q_conv.weight"], sd[p + ".q_conv.bias"]).reshape(b, h * w, 1)
+    k = F.conv2d(att, sd[p + ".k_conv.weight"], sd[p + ".k_conv.bias"]).reshape(b, 1, h * w)
+    a = F.softmax(q @ k, dim=-1) @ att.reshape(b, h * w, 1)
+    return F.softsign(a.reshape(b, 1, h, w)) * x
+
+
+def pos_sine(b, h, w, d, device=None):
+    """PositionEmbeddingSine on a [b, h, w, d] tensor, normalize=False (cond_unet_sd.py:16-65): cat(pos_y, pos_x)."""
+    npf = d // 2
+    y = torch.arange(1, h + 1, dtype=torch.float32, device=device)[None, :, None].expand(b, h, w)
+    x = torch.arange(1, w + 1, dtype=torch.float32, device=device)[None, None, :].expand(b, h, w)
+    dim_t = torch.arange(npf, dtype=torch.float32, device=device)
+    dim_t = 10000 ** (2 * (dim_t // 2) / npf)
+    px, py = x[..., None] / dim_t, y[..., None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3)
+
+
+def batch_norm(sd, p, x, training, momentum=0.03, eps=1e-3, update=None):
+    """nn.BatchNorm2d(momentum=0.03, eps=0.001) of RelationNet.input_conv{1,2} (cond_unet_sd.py:247-254).  In training mode
+    batch statistics normalise and, when `update` (a dict) is given, the new running statistics are returned in it."""
+    if not training:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
+    mean = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    if update is not None:
+        n = x.numel() // x.shape[1]
+        update[p + ".running_mean"] = (1 - momentum) * sd[p + ".running_mean"] + momentum * mean.detach()
+        update[p + ".running_var"] = (1 - momentum) * sd[p + ".running_var"] + momentum * var.detach() * n / max(n - 1, 1)
+    xh = (x - mean[None, :, None, None]) * torch.rsqrt(var[None, :, None, None] + eps)
+    return xh * sd[p + ".weight"][None, :, None, None] + sd[p + ".bias"][None, :, None, None]
+
+
+def basic_attention_layer(sd, p, x1, x2, win1, win2, nhead=8, training=False, drop_masks=None):
+    """BasicAttetnionLayer.forward (cond_unet_sd.py:191-238): x1 = condition feature (queries), x2 = UNet feature (keys /
+    values).  Dropout (p = 0.1 on the Mlp, cond_unet_sd.py:167) is the identity unless `drop_masks` = (m1, m2) scaled keep
+    masks are injected."""
+    B, C1, H1, W1 = x1.shape
+    _, C2, H2, W2 = x2.shape
+    up = F.interpolate(x1, size=(H2, W2), mode="bilinear", align_corners=True)
+    shortcut = x2 + F.conv2d(torch.cat([up, x2], dim=1), sd[p + ".concat_conv.weight"], sd[p + ".concat_conv.bias"])
+    shortcut = F.group_norm(shortcut, 8, sd[p + ".gn.weight"], sd[p + ".gn.bias"], 1e-5)
+    x1 = F.pad(x1, (0, (win1[1] - W1 % win1[1]) % win1[1], 0, (win1[0] - H1 % win1[0]) % win1[0]))
+    x2 = F.pad(x2, (0, (win2[1] - W2 % win2[1]) % win2[1], 0, (win2[0] - H2 % win2[0]) % win2[0]))
+    x1_s = F.avg_pool2d(x1, tuple(win1))
+    qg = x1_s.permute(0, 2, 3, 1)
+    qg = (qg + pos_sine(*qg.shape, device=qg.device)).reshape(B, -1, C2)
+    kg = F.avg_pool2d(x2, tuple(win2)).permute(0, 2, 3, 1)
+    kg = (kg + pos_sine(*kg.shape, device=kg.device)).reshape(B, -1, C1)
+    nq, nk, dh = qg.shape[1], kg.shape[1], C1 // nhead
+    q = F.linear(qg, sd[p + ".q_lin.weight"], sd[p + ".q_lin.bias"]).reshape(B, nq, nhead, dh).permute(0, 2, 1, 3)
+    k = F.linear(kg, sd[p + ".k_lin.weight"], sd[p + ".k_lin.bias"]).reshape(B, nk, nhead, dh).permute(0, 2, 1, 3)
+    v = F.linear(kg, sd[p + ".v_lin.weight"], sd[p + ".v_lin.bias"]).reshape(B, nk, nhead, dh).permute(0, 2, 1, 3)
+    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)          # NOTE: no 1/sqrt(d) scaling in the reference
+    o = (attn @ v).transpose(1, 2).reshape(B, nq, C1).transpose(1, 2).reshape(B, C1, x1_s.shape[2], x1_s.shape[3])
+    x1_s = x1_s + o
+    m = F.relu(F.conv2d(x1_s, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"]))
+    if training and drop_masks is not None:
+        m = m * drop_masks[0]
+    m = F.conv2d(m, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    if training and drop_masks is not None:
+        m = m * drop_masks[1]
+    x1_s = x1_s + m
+    x1_s = F.interpolate(x1_s, size=(H2, W2), mode="bilinear", align_corners=True)
+    return shortcut + F.conv2d(x1_s, sd[p + ".out_conv.weight"], sd[p + ".out_conv.bias"])
+
+
+def relation_net(sd, p, cond, feat, win1, win2, training=False, bn_update=None):
+    """RelationNet.forward with layers = 1 (cond_unet_sd.py:240-279)."""
+    cond = F.conv2d(cond, sd[p + ".input_conv1.0.weight"], sd[p + ".input_conv1.0.bias"])
+    cond = batch_norm(sd, p + ".input_conv1.1", cond, training, update=bn_update)
+    feat = F.conv2d(feat, sd[p + ".input_conv2.0.weight"], sd[p + ".input_conv2.0.bias"])
+    feat = batch_norm(sd, p + ".input_conv2.1", feat, training, update=bn_update)
+    return basic_attention_layer(sd, p + ".attentions.0", cond, feat, win1, win2, training=training)
+
+
+# ------------------------------------------------------------------------------------------------ the network
+def default_cfg(**over):
+    """configs/super-resolution/div2k_cond_ddm_const_ldm.yaml:41-58 (f_cond = 128 is Swin-B's first-stage width)."""
+    cfg = dict(dim=128, dim_mults=(1, 2, 4, 4), channels=3, f_cond=128, window_sizes1=[[8, 8], [4, 4], [2, 2], [1, 1]],
+               window_sizes2=[[4, 4], [2, 2], [1, 1], [1, 1]], fourier_scale=16, two_decoders=False, precondition=True)
+    cfg.update(over)
+    return cfg
+
+
+def param_shapes(cfg):
+    """state_dict name -> shape, in the reference's registration order, WITHOUT the condition encoder `init_conv_mask.*`
+    (checked against the imported reference in tools/make_golden_cond.py)."""
+    dim, mults, ch, f = cfg["dim"], cfg["dim_mults"], cfg["channels"], cfg["f_cond"]
+    dims = [dim] + [dim * m for m in mults]
+    in_out = list(zip(dims[:-1], dims[1:]))
+    tdim = dim * 4
+    s = {}
+
+    def conv(p, co, ci, k, bias=True):
+        s[p + ".weight"] = (co, ci, k, k)
+        if bias:
+            s[p + ".bias"] = (co,)
+
+    def norm(p, c):
+        s[p + ".weight"] = (c,); s[p + ".bias"] = (c,)
+
+    def lin(p, co, ci):
+        s[p + ".weight"] = (co, ci); s[p + ".bias"] = (co,)
+
+    def resblock(p, ci, co):
+        lin(p + ".mlp.1", 2 * co, tdim)
+        conv(p + ".block1.proj", co, ci, 3); norm(p + ".block1.norm", co)
+        conv(p + ".block2.proj", co, co, 3); norm(p + ".block2.norm", co)
+        if ci != co:
+            conv(p + ".res_conv", co, ci, 1)
+
+    def lin_attn(p, c):
+        conv(p + ".fn.fn.to_qkv", 384, c, 1, bias=False)
+        conv(p + ".fn.fn.to_out.0", c, 128, 1)
+        s[p + ".fn.fn.to_out.1.g"] = (1, c, 1, 1)
+        s[p + ".fn.norm.g"] = (1, c, 1, 1)
+
+    def relation(p, c1, c2, e):
+        for name, cin in (("input_conv1", c1), ("input_conv2", c2)):
+            conv(p + f".{name}.0", e, cin, 1)
+            norm(p + f".{name}.1", e)
+            s[p + f".{name}.1.running_mean"] = (e,); s[p + f".{name}.1.running_var"] = (e,)
+            s[p + f".{name}.1.num_batches_tracked"] = ()
+        a = p + ".attentions.0"
+        for n in ("q_lin", "k_lin", "v_lin"):
+            lin(a + "." + n, e, e)
+        conv(a + ".mlp.fc1", 2 * e, e, 1); conv(a + ".mlp.fc2", e, 2 * e, 1)
+        conv(a + ".concat_conv", e, 2 * e, 1); norm(a + ".gn", e); conv(a + ".out_conv", e, e, 1)
+
+    conv("init_conv.0", dim, ch + f, 7); norm("init_conv.1", dim)
+    for i in range(4):
+        conv(f"projects.{i}", dims[i], f * 2 ** i, 1)
+    s["time_mlp.0.W"] = (dim // 2,)
+    lin("time_mlp.1", tdim, dim); lin("time_mlp.3", tdim, tdim)
+    n = len(in_out)
+    for i, (ci, co) in enumerate(in_out):
+        resblock(f"downs.{i}.0", ci, ci); resblock(f"downs.{i}.1", ci, ci); lin_attn(f"downs.{i}.2", ci)
+        conv(f"downs.{i}.3", co, ci, 4 if i < n - 1 else 3)
+    decs = ["ups", "ups2"] if cfg["two_decoders"] else ["ups"]
+    for d in decs:
+        for i, (ci, co) in enumerate(reversed(in_out)):
+            resblock(f"{d}.{i}.0", co + ci, co); resblock(f"{d}.{i}.1", co + ci, co); lin_attn(f"{d}.{i}.2", co)
+            conv(f"{d}.{i}.3.1" if i < n - 1 else f"{d}.{i}.3", ci, co, 3)
+    for i in range(n):
+        relation(f"relation_layers_down.{i}", dims[i], dims[i], dims[i])
+    rev = dims[::-1]
+    for i in range(n):
+        relation(f"relation_layers_up.{i}", rev[i + 1], rev[i], rev[i])
+    if cfg["two_decoders"]:
+        for i in range(n):
+            relation(f"relation_layers_up2.{i}", rev[i + 1], rev[i], rev[i])
+    mid = dims[-1]
+    resblock("mid_block1", mid, mid)
+    conv("mid_attn.fn.fn.to_qkv", 384, mid, 1, bias=False); conv("mid_attn.fn.fn.to_out", mid, 128, 1)
+    s["mid_attn.fn.norm.g"] = (1, mid, 1, 1)
+    resblock("mid_block2", mid, mid)
+    for d in (["decouple1", "decouple2"] if cfg["two_decoders"] else ["decouple1"]):
+        norm(d + ".0", mid); conv(d + ".1", mid, mid, 3)
+        conv(d + ".2.map", 1, mid, 1); conv(d + ".2.q_conv", 1, 1, 1); conv(d + ".2.k_conv", 1, 1, 1)
+    resblock("final_res_block", 2 * dim, dim); conv("final_conv", ch, dim, 1)
+    if cfg["two_decoders"]:
+        resblock("final_res_block2", 2 * dim, dim); conv("final_conv2", ch, dim, 1)
+    return s
+
+
+def _decouple(sd, p, x):
+    g = min(x.shape[1] // 4, 8)
+    h = F.group_norm(x, g, sd[p + ".0.weight"], sd[p + ".0.bias"], 1e-5)
+    h = F.conv2d(h, sd[p + ".1.weight"], sd[p + ".1.bias"], padding=1)
+    return spatial_att(sd, p + ".2", h)
+
+
+def unet_forward(sd, cfg, x, time, hm, training=False, bn_update=None):
+    """Unet.forward (cond_unet_sd.py:801-883; two decoders: cond_unet.py:823-918) with the condition-encoder outputs `hm`
+    (list of 4 NCHW tensors) injected in place of `self.init_conv_mask(mask)`.  Returns (x1, x2) = (C_pred, noise_pred)."""
+    x = x.to(torch.float32)
+    time = torch.as_tensor(time).to(torch.float32).reshape(-1)
+    t = time.reshape(-1, 1, 1, 1)
+    x_clone = x
+    n = len(cfg["dim_mults"])
+    w1, w2 = cfg["window_sizes1"], cfg["window_sizes2"]
+    g0 = min(cfg["dim"] // 4, 8)
+    xin = torch.cat([x, F.interpolate(hm[0], size=x.shape[-2:], mode="bilinear")], dim=1)
+    x = F.group_norm(F.conv2d(xin, sd["init_conv.0.weight"], sd["init_conv.0.bias"], padding=3), g0,
+                     sd["init_conv.1.weight"], sd["init_conv.1.bias"], 1e-5)
+    r = x
+    t_emb = time_mlp(sd, time.log())
+    hm = [F.conv2d(hm[i], sd[f"projects.{i}.weight"], sd[f"projects.{i}.bias"]) for i in range(4)]
+    h = []
+    for i in range(n):
+        x = resnet_block(sd, f"downs.{i}.0", x, t_emb)
+        h.append(x)
+        x = relation_net(sd, f"relation_layers_down.{i}", hm[i], x, w1[i], w2[i], training, bn_update)
+        x = resnet_block(sd, f"downs.{i}.1", x, t_emb)
+        x = linear_attention(sd, f"downs.{i}.2.fn", x)
+        h.append(x)
+        wk = sd[f"downs.{i}.3.weight"]
+        x = F.conv2d(x, wk, sd[f"downs.{i}.3.bias"], stride=2, padding=1) if wk.shape[-1] == 4 else \
+            F.conv2d(x, wk, sd[f"downs.{i}.3.bias"], padding=1)
+    x = resnet_block(sd, "mid_block1", x, t_emb)
+    x = full_attention(sd, "mid_attn.fn", x)
+    xm = resnet_block(sd, "mid_block2", x, t_emb)
+
+    def decode(dec, rel, dcp, frb, fc):
+        x = xm + _decouple(sd, dcp, xm)
+        hs, hms = list(h), list(hm)
+        for i in range(n):
+            x = torch.cat((x, hs.pop()), dim=1)
+            x = resnet_block(sd, f"{dec}.{i}.0", x, t_emb)
+            x = relation_net(sd, f"{rel}.{i}", hms.pop(), x, w1[::-1][i], w2[::-1][i], training, bn_update)
+            x = torch.cat((x, hs.pop()), dim=1)
+            x = resnet_block(sd, f"{dec}.{i}.1", x, t_emb)
+            x = linear_attention(sd, f"{dec}.{i}.2.fn", x)
+            if i < n - 1:
+                x = F.interpolate(x, scale_factor=2, mode="nearest")
+                x = F.conv2d(x, sd[f"{dec}.{i}.3.1.weight"], sd[f"{dec}.{i}.3.1.bias"], padding=1)
+            else:
+                x = F.conv2d(x, sd[f"{dec}.{i}.3.weight"], sd[f"{dec}.{i}.3.bias"], padding=1)
+        x = resnet_block(sd, frb, torch.cat((x, r), dim=1), t_emb)
+        return F.conv2d(x, sd[fc + ".weight"], sd[fc + ".bias"])
+
+    f1 = decode("ups", "relation_layers_up", "decouple1", "final_res_block", "final_conv")
+    x1 = ((t - 1) * x_clone + t / (t + 1).sqrt() * f1) if cfg["precondition"] else f1
+    if cfg["two_decoders"]:        # cond_unet.py:914-916
+        f2 = decode("ups2", "relation_layers_up2", "decouple2", "final_res_block2", "final_conv2")
+        x2 = (t.sqrt() * x_clone + (1 - t).sqrt() / (1 + t).sqrt() * f2) if cfg["precondition"] else f2
+    else:                          # cond_unet_sd.py:878-882
+        x2 = (x_clone - (t - 1) * x1) / t.sqrt()
+    return x1, x2
+
+
+# ------------------------------------------------------------------------------------------------ sliding-window stitching
+def slide_windows(h_cond, w_cond, crop, stride):
+    """Window origins of Sampler.slide_sample_sr (/root/reference/sample_cond_ldm.py:281-330), as (y1, y2, x1, x2)."""
+    (hc, wc), (hs, ws) = crop, stride
+    hg = max(h_cond - hc + hs - 1, 0) // hs + 1
+    wg = max(w_cond - wc + ws - 1, 0) // ws + 1
+    out = []
+    for hi in range(hg):
+        for wi in range(wg):
+            y2 = min(hi * hs + hc, h_cond); x2 = min(wi * ws + wc, w_cond)
+            out.append((max(y2 - hc, 0), y2, max(x2 - wc, 0), x2))
+    return out
+
+
+def slide_sample_sr(sample_fn, cond, image_hw, crop, stride, out_channels=3, scale=4, ori_size=None):
+    """Overlap-average stitching of per-window samples (sample_cond_ldm.py:281-330): sample_fn(crop_of_cond) -> the 4x larger
+    output crop; every output pixel is the mean over the windows covering it."""
+    B = cond.shape[0]
+    H, W = image_hw
+    preds = cond.new_zeros((B, out_channels, H, W))
+    count = cond.new_zeros((B, out_channels, H, W))
+    for (y1, y2, x1, x2) in slide_windows(cond.shape[2], cond.shape[3], crop, stride):
+        out = sample_fn(cond[:, :, y1:y2, x1:x2])
+        preds += F.pad(out, (x1 * scale, W - x2 * scale, y1 * scale, H - y2 * scale))
+        count[:, :, y1 * scale:y2 * scale, x1 * scale:x2 * scale] += 1
+    assert (count == 0).sum() == 0
+    res = preds / count
+    return res if ori_size is None else res[:, :, :ori_size[0], :ori_size[1]]
+
+
+# ------------------------------------------------------------------------------------------------ deterministic fill
+def cond_fill_value(name, shape):
+    """fill.fill_value extended to the leaves this network adds (LayerNorm gains `.g`, the fixed Fourier frequencies `.W`,
+    BatchNorm running statistics, GroupNorm / BatchNorm affine pairs that are not called '.norm')."""
+    from . import fill
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "g":
+        return 1.0 + fill.hash_tensor(shape, name, 0.2)
+    if leaf == "W":
+        return fill.hash_tensor(shape, name, 4.0)
+    if leaf == "running_mean":
+        return fill.hash_tensor(shape, name, 0.1)
+    if leaf == "running_var":
+        return 1.0 + fill.hash_tensor(shape, name, 0.3)
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.long)
+    normish = (".gn." in name or ".input_conv1.1." in name or ".input_conv2.1." in name or name.startswith("init_conv.1.")
+               or name.startswith("decouple1.0.") or name.startswith("decouple2.0."))
+    if leaf == "weight" and normish:
+        return 1.0 + fill.hash_tensor(shape, name, 0.2)
+    if leaf == "weight" and (".q_lin." in name or ".k_lin." in name):
+        return fill.hash_tensor(shape, name, 3.0 * (1.0 / shape[1]) ** 0.5)       # a non-uniform softmax
+    return fill.fill_value(name, shape)
+
+
+def filled_state_dict(cfg):
+    return {k: cond_fill_value(k, tuple(s)) for k, s in param_shapes(cfg).items()}
+
+
+def cond_features(B, H, W, f=128, tag="hm"):
+    """Deterministic stand-ins for the Swin-B feature pyramid of a condition image of size H x W (inputs of the tests)."""
+    from . import fill
+    return [fill.hash_tensor((B, f * 2 ** i, max(H // (4 << i), 1), max(W // (4 << i), 1)), f"{tag}{i}", 1.0) for i in range(4)]
