@@ -89,7 +89,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
     // input image; a strided conv (the KL autoencoder's Downsample) moves it to oy*stride + (1 - pad_lo)
     const int cy = UP ? oy : oy * p.stride + p.cshift, cx = UP ? ox : ox * p.stride + p.cshift;
     const int HB = UP ? p.H : p.Hin, WB = UP ? p.W : p.Win;
-    if (ok) {
+    if (p.ks > 3) {
+      // generic filter (7x7 stem, 4x4 stride-2 down-conv of the conditional UNet): keep the centre coordinates, biased by
+      // 64 so that a negative centre (pad_lo > ks/2 never happens, but cshift may be 0 with ky - pad_lo < 0) stays unsigned;
+      // validity is evaluated per tap in issue_stage.  Rows past M get a centre no tap can bring into the image.
+      mask = ok ? (((unsigned)(cy + 64) << 16) | (unsigned)(cx + 64)) : 0xFFFFFFFFu;
+    } else if (ok) {
       if (p.ks == 3) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
       }
     }
     // for the fused nearest-x2 the tap offset depends on the parity of (oy, ox): keep it in the high bits
-    if (UP) mask |= ((unsigned)(oy & 1) << 16) | ((unsigned)(ox & 1) << 17);
+    if (UP) mask |= ((unsigned)(oy & 1) << 16) | ((unsigned)(ox & 1) << 17);      // (UP implies ks <= 3: checked on the host)
     a_mask[i] = mask;
     int py = UP ? (oy >> 1) : cy, px = UP ? (ox >> 1) : cx;
     a_pix[i] = (unsigned)(((b * p.Hin + py) * p.Win + px) * p.ldx + ls * 4) * 4u;     // byte offset of the centre pixel
@@ -131,10 +136,16 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IgemmP p) {
     if (ld_cc == 0 || a_fresh) {   // new tap: rebuild the per-row offsets (wave-uniform branch, every Cin/32 steps)
       a_fresh = false;
       int dy = 0, dx = 0;
-      if (p.ks == 3) { dy = tap / 3 - pad; dx = tap - (tap / 3) * 3 - pad; }
+      if (p.ks >= 3) { dy = tap / p.ks - pad; dx = tap - (tap / p.ks) * p.ks - pad; }
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        const bool v = (a_mask[i] >> tap) & 1u;
+        bool v;
+        if (p.ks > 3) {
+          const int iy = (int)(a_mask[i] >> 16) - 64 + dy, ix = (int)(a_mask[i] & 0xFFFFu) - 64 + dx;
+          v = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        } else {
+          v = (a_mask[i] >> tap) & 1u;
+        }
         int off = (dy * p.Win + dx) * p.ldx;
         if (UP) {   // input pixel of output (oy+dy, ox+dx) is ((oy+dy)>>1, (ox+dx)>>1): floor((parity + d) / 2)
           int py = (int)((a_mask[i] >> 16) & 1u), px = (int)((a_mask[i] >> 17) & 1u);
@@ -305,8 +316,9 @@ int conv_fwd_impl(const float* x, const float* wp, const float* bias, const floa
                   int Hin, int Win, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks, int up, int stride,
                   int pad_lo, int tile, hipStream_t stream) {
   if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || Hin <= 0 || Win <= 0) return ADM_EINVAL;
-  if ((Cin & 31) || (ldx & 3) || (ks != 1 && ks != 3) || N <= 0 || wrows < N) return ADM_EINVAL;
-  if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
+  if ((Cin & 31) || (ldx & 3) || ks < 1 || ks > 7 || N <= 0 || wrows < N) return ADM_EINVAL;
+  if (up && ((H & 1) || (W & 1) || ks > 3)) return ADM_EINVAL;
+  if (ks > 3 && (Hin >= 32000 || Win >= 32000)) return ADM_EINVAL;      // packed 16-bit centre coordinates
   if (((uintptr_t)x | (uintptr_t)wp) & 15) return ADM_EINVAL;
   if ((long)B * H * W >= (1L << 31)) return ADM_EINVAL;
   IgemmP p;
@@ -361,6 +373,7 @@ extern "C" int adm_conv_fwd_strided(const float* x, const float* wp, const float
                                     int B, int Hin, int Win, int Hout, int Wout, int Cin, int ldx, int N, int wrows,
                                     int ldy, int ldr, int ks, int stride, int pad_lo, hipStream_t stream) {
   if (stride < 1 || stride > 4 || pad_lo < 0 || pad_lo > (ks >> 1) || Hout <= 0 || Wout <= 0) return ADM_EINVAL;
+  if (ks == 2) return ADM_EINVAL;
   if ((long)(Hout - 1) * stride - pad_lo >= Hin || (long)(Wout - 1) * stride - pad_lo >= Win) return ADM_EINVAL;
   return conv_fwd_impl(x, wp, bias, res, y, B, Hout, Wout, Hin, Win, Cin, ldx, N, wrows, ldy, ldr, ks, 0, stride,
                        pad_lo, -1, stream);

@@ -26,6 +26,7 @@ namespace {
 struct WgradP {
   const float* x; const float* dy; float* dwp;
   int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes;
+  int stride, pad_lo;      // generic path: tap (ky, kx) of output (oy, ox) reads input (oy*stride + ky - pad_lo, ox*stride + kx - pad_lo)
   float* dbias;      // optional: dbias[co] += sum_p dY[p][co] (the conv's bias gradient), by the tap-0 / ci-tile-0 workgroups
   // deterministic mode (split_stride > 0): split z stores its partial tile at dwp + z * split_stride and its bias partial at
   // dbias + z * bias_stride with plain stores; adm_unpack_wgrad_splits sums the splits in a fixed order
@@ -49,7 +50,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
   const int co0 = tm * TM, ci0 = tn * TN;
   const int tap = blockIdx.y;
   const int pad = p.ks >> 1;
-  const int dy_ = (p.ks == 3) ? tap / 3 - pad : 0, dx_ = (p.ks == 3) ? tap % 3 - pad : 0;
+  // offsets relative to the output pixel scaled by the stride: (ky - pad_lo, kx - pad_lo); = tap - ks/2 for the 'same' convs
+  const int dy_ = tap / p.ks - p.pad_lo, dx_ = tap % p.ks - p.pad_lo;
+  (void)pad;
   const int pbeg = blockIdx.z * p.chunk;
   const int pend = min(p.P, pbeg + p.chunk);
   if (pbeg >= pend) return;
@@ -134,8 +137,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradP p) {
         int t = pp / p.W;
         int oy = t % p.H;
         int b = t / p.H;
-        int iy = oy + dy_, ix = ox + dx_;
-        bool v = pp < pend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && b_colb[i] != OOB;
+        int iy = oy * p.stride + dy_, ix = ox * p.stride + dx_;
+        // bounds in the grid the taps walk on: the up-sampled grid for `up`, else the (possibly larger, strided) input image
+        const int HB = p.up ? p.H : p.Hin, WB = p.up ? p.W : p.Win;
+        bool v = pp < pend && (unsigned)iy < (unsigned)HB && (unsigned)ix < (unsigned)WB && b_colb[i] != OOB;
         if (p.up) { iy >>= 1; ix >>= 1; }
         unsigned voff = v ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.ldx) * 4u + b_colb[i] : OOB;
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0));
@@ -238,7 +243,7 @@ template <int TM, int TN>
 int launch_wgrad(WgradP p, int splits, hipStream_t st) {
   p.tilesN = adm_cdiv(p.Cin, TN);
   dim3 grid(adm_cdiv(p.Cout, TM) * p.tilesN, p.ks * p.ks, splits);
-  const bool fast = p.lw >= 0 && p.W <= 32 && !p.up;       // see load_stage
+  const bool fast = p.lw >= 0 && p.W <= 32 && !p.up && p.stride == 1;       // see load_stage
   if (fast) hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN, true>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN, false>), grid, dim3(256), 0, st, p);
   ADM_CHECK_LAUNCH();
@@ -250,17 +255,21 @@ int launch_wgrad(WgradP p, int splits, hipStream_t st) {
 namespace {
 // plan_only: return the split count the launcher would pick.  split_stride > 0: deterministic workspace mode.
 int wgrad_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-               int lddy, int ks, int up, int splits, long split_stride, long bias_stride, bool plan_only, hipStream_t stream) {
+               int lddy, int ks, int up, int splits, long split_stride, long bias_stride, bool plan_only, hipStream_t stream,
+               int stride = 1, int pad_lo = -1, int Hin = 0, int Win = 0) {
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
   if (B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
-  if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3) || (ks != 1 && ks != 3)) return ADM_EINVAL;
-  if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
+  if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3) || ks < 1 || ks > 7) return ADM_EINVAL;
+  if (up && ((H & 1) || (W & 1) || ks > 3 || stride != 1)) return ADM_EINVAL;
+  if (pad_lo < 0) pad_lo = ks >> 1;
+  if (stride < 1 || stride > 4) return ADM_EINVAL;
   if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
   WgradP p;
   p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
-  p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
+  p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : (Hin > 0 ? Hin : H); p.Win = up ? W / 2 : (Win > 0 ? Win : W);
   p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.ks = ks; p.up = up; p.tilesN = 0;
-  p.split_stride = split_stride; p.bias_stride = bias_stride;
+  p.split_stride = split_stride; p.bias_stride = bias_stride; p.stride = stride; p.pad_lo = pad_lo;
+  if (stride == 1 && (p.Hin != (up ? H / 2 : H) || p.Win != (up ? W / 2 : W))) return ADM_EINVAL;
   const long xb = (long)B * p.Hin * p.Win * ldx * 4, db = (long)p.P * lddy * 4;
   if (xb >= (1L << 31) || db >= (1L << 31)) return ADM_EINVAL;      // 32-bit buffer offsets
   p.xbytes = (int)xb; p.dybytes = (int)db;
@@ -329,4 +338,15 @@ extern "C" int adm_conv_wgrad_ws(const float* x, const float* dy, float* ws, flo
   }
   return wgrad_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, (long)Cout * ks * ks * Cin, Cout, false,
                     stream);
+}
+
+// Weight gradient of a strided conv with explicit top/left padding (the conditional UNet's Downsample = Conv2d(C, C', 4, 2, 1),
+// /root/reference/unet/cond_unet_sd.py:341-342): dy is [B][Hout][Wout][Cout], x is [B][Hin][Win][Cin]; tap (ky, kx) of output
+// (oy, ox) reads x(oy*stride + ky - pad_lo, ox*stride + kx - pad_lo), zero outside.  dwp[Cout][ks*ks][Cin] as adm_conv_wgrad.
+extern "C" int adm_conv_wgrad_strided(const float* x, const float* dy, float* dwp, float* dbias, int B, int Hin, int Win, int Hout,
+                                      int Wout, int Cin, int ldx, int Cout, int lddy, int ks, int stride, int pad_lo,
+                                      hipStream_t stream) {
+  if (Hin <= 0 || Win <= 0 || pad_lo < 0 || pad_lo >= ks) return ADM_EINVAL;
+  if ((long)(Hout - 1) * stride - pad_lo >= Hin || (long)(Wout - 1) * stride - pad_lo >= Win) return ADM_EINVAL;
+  return wgrad_impl(x, dy, dwp, dbias, B, Hout, Wout, Cin, ldx, Cout, lddy, ks, 0, 0, 0, 0, false, stream, stride, pad_lo, Hin, Win);
 }

@@ -301,24 +301,31 @@ __global__ __launch_bounds__(256) void ddm_loss_latent_kernel(const float* __res
                                                               const float* __restrict__ xt, const float* __restrict__ t,
                                                               const float* __restrict__ w, float* __restrict__ per_sample,
                                                               float* __restrict__ per_l1, float* __restrict__ dc,
-                                                              float* __restrict__ dn, float gscale, long n) {
+                                                              float* __restrict__ dn, float gscale, long n, int schedule,
+                                                              int use_l1) {
   __shared__ float red[8];
   const int b = blockIdx.x;
   const float w1 = w[3 * b], w2 = w[3 * b + 1], w3 = w[3 * b + 2], tb = t[b];
+  const float gt = schedule == 0 ? sqrtf(tb) : tb;       // 'const': sqrt(t) (ddm_const.py:290-293); 'const_2': t
   float acc = 0.f, l1 = 0.f;
   for (long i = blockIdx.y * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.y * blockDim.x) {
     long k = (long)b * n + i;
     float c = cp[k], e = np_[k];
     float e1 = c + x0[k];
     float e2 = e - noise[k];
-    float d = ((xt[k] - c * tb) - tb * e) - x0[k];
-    acc += w1 * e1 * e1 + w2 * e2 * e2;
+    float d = ((xt[k] - c * tb) - gt * e) - x0[k];
+    // use_l1 (ddm_const_2.py:556-559): loss_simple = [w1 (SSE_C + L1_C) + w2 (SSE_eps + L1_eps)] / 2
+    acc += use_l1 ? 0.5f * (w1 * (e1 * e1 + fabsf(e1)) + w2 * (e2 * e2 + fabsf(e2))) : w1 * e1 * e1 + w2 * e2 * e2;
     l1 += fabsf(d);
     if (dc) {
-      float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-      float g3 = -w3 * tb * sg;
-      dc[k] = gscale * (2.f * w1 * e1 + g3);
-      dn[k] = gscale * (2.f * w2 * e2 + g3);
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      float g1 = 2.f * w1 * e1, g2 = 2.f * w2 * e2;
+      if (use_l1) {
+        g1 = 0.5f * (g1 + w1 * (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f)));
+        g2 = 0.5f * (g2 + w2 * (e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f)));
+      }
+      dc[k] = gscale * (g1 - w3 * tb * sg);
+      dn[k] = gscale * (g2 - w3 * gt * sg);
     }
   }
   acc = wave_sum(acc); l1 = wave_sum(l1);
@@ -663,8 +670,10 @@ extern "C" int adm_ddm_loss(const float* c_pred, const float* n_pred, const floa
 
 extern "C" int adm_ddm_loss_latent(const float* c_pred, const float* n_pred, const float* x0, const float* noise,
                                    const float* xt, const float* t, const float* w, float* per_sample, float* per_l1,
-                                   float* d_c, float* d_n, float gscale, int B, long n, hipStream_t stream) {
+                                   float* d_c, float* d_n, float gscale, int B, long n, int schedule, int use_l1,
+                                   hipStream_t stream) {
   if (!c_pred || !n_pred || !x0 || !noise || !xt || !t || !w || !per_sample || !per_l1 || B <= 0 || n <= 0) return ADM_EINVAL;
+  if (schedule != 0 && schedule != 1) return ADM_EINVAL;
   if ((d_c == nullptr) != (d_n == nullptr)) return ADM_EINVAL;
   if (hipMemsetAsync(per_sample, 0, sizeof(float) * B, stream) != hipSuccess) return ADM_ELAUNCH;
   if (hipMemsetAsync(per_l1, 0, sizeof(float) * B, stream) != hipSuccess) return ADM_ELAUNCH;
@@ -672,7 +681,7 @@ extern "C" int adm_ddm_loss_latent(const float* c_pred, const float* n_pred, con
   if (chunks > 64) chunks = 64;
   if (n <= 65536) chunks = 1;
   hipLaunchKernelGGL(ddm_loss_latent_kernel, dim3(B, chunks), dim3(256), 0, stream, c_pred, n_pred, x0, noise, xt, t, w,
-                     per_sample, per_l1, d_c, d_n, gscale, n);
+                     per_sample, per_l1, d_c, d_n, gscale, n, schedule, use_l1);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

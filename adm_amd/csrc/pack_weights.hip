@@ -190,7 +190,7 @@ extern "C" int adm_pack_weight_table(const long* table, int n_entries, long tota
 
 extern "C" int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci, int ks, int Co_pad,
                                int Ci_pad, int qkv, hipStream_t stream) {
-  if (!w || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3) || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  if (!w || Co <= 0 || Ci <= 0 || ks < 1 || ks > 7 || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
   if (qkv && (Co % 192 != 0 || Co_pad != Co)) return ADM_EINVAL;
   int taps = ks * ks;
   long total = (long)Co_pad * taps * Ci_pad;
@@ -203,7 +203,7 @@ extern "C" int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int
 
 extern "C" int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
                                 int accumulate, hipStream_t stream) {
-  if (!dwp || !dw || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3) || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  if (!dwp || !dw || Co <= 0 || Ci <= 0 || ks < 1 || ks > 7 || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
   if (qkv && (Co % 192 != 0)) return ADM_EINVAL;
   int taps = ks * ks;
   long total = (long)Co * Ci * taps;
@@ -228,7 +228,7 @@ __global__ void bias_splits_kernel(const float* __restrict__ bws, float* __restr
 // dbias[0..Co_pad) (+=, the packed channel order the atomic path accumulates in).  bws / dbias may be NULL.
 extern "C" int adm_unpack_wgrad_splits(const float* ws, int splits, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad,
                                        int qkv, int accumulate, const float* bws, float* dbias, hipStream_t stream) {
-  if (!ws || !dw || splits < 1 || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3) || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  if (!ws || !dw || splits < 1 || Co <= 0 || Ci <= 0 || ks < 1 || ks > 7 || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
   if (qkv && (Co % 192 != 0)) return ADM_EINVAL;
   if ((bws == nullptr) != (dbias == nullptr)) return ADM_EINVAL;
   int taps = ks * ks;
@@ -262,6 +262,31 @@ extern "C" int adm_colsum(const float* a, float* out, int M, int N, int ld, int 
   int rows = adm_cdiv(M, chunks);
   chunks = adm_cdiv(M, rows);
   hipLaunchKernelGGL(colsum_kernel, dim3(strips, chunks), dim3(256), 0, stream, a, out, M, N, ld, rows);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+namespace {
+// out[(tap * Ci_pad + ci)][co] = w[co][ci][tap]: the B operand (rows = (tap, ci), K = co contiguous) of the GEMM form of a
+// transposed convolution, col[m][(tap, ci)] = sum_co dy[m][co] w[co][ci][tap]
+__global__ void pack_tconv_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int Ci, int taps, int Co_pad,
+                                  int Ci_pad) {
+  const long total = (long)taps * Ci_pad * Co_pad;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int co = idx % Co_pad;
+    const long t = idx / Co_pad;
+    const int ci = t % Ci_pad, tap = t / Ci_pad;
+    out[idx] = (co < Co && ci < Ci) ? w[((long)co * Ci + ci) * taps + tap] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int adm_pack_weight_tconv(const float* w, float* out, int Co, int Ci, int ks, int Co_pad, int Ci_pad,
+                                     hipStream_t stream) {
+  if (!w || !out || Co <= 0 || Ci <= 0 || ks < 1 || ks > 7 || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  const long total = (long)ks * ks * Ci_pad * Co_pad;
+  hipLaunchKernelGGL(pack_tconv_kernel, dim3((unsigned)min((long)4096, (total + 255) / 256)), dim3(256), 0, stream, w, out, Co, Ci,
+                     ks * ks, Co_pad, Ci_pad);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

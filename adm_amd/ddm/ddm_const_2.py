@@ -24,6 +24,8 @@ class DDPM(DDPMBase):
 
 class LatentDiffusion(DDPM):
     USES_LPIPS = False
+    SUPPORTS_L1 = True
+    CLIP_IN_SAMPLER = False
 
     def __init__(self, auto_encoder, scale_factor=1.0, scale_by_std=True, scale_by_softsign=False, input_keys=("image",),
                  sample_type="naive", default_scale=False, *args, **kwargs):
@@ -97,12 +99,12 @@ class LatentDiffusion(DDPM):
     def training_step(self, batch, *, eps: Optional[torch.Tensor] = None, **kwargs):
         """`eps` (posterior draw), and via kwargs `t` / `noise`, are injectable for parity tests."""
         z, c, x, *_ = self.get_input(batch, eps=eps)
-        if c is not None:
-            raise NotImplementedError("conditional latent diffusion is not on the unconditional hot path")
         if self.scale_by_softsign:
             z = F.softsign(z)
         elif self.scale_by_std:
             z = self.scale_factor * z
+        if c is not None:          # conditional denoiser (super-resolution): model(x_t, t, cond)   (ddm_const_2.py:512-524)
+            return self(z, c, **kwargs)
         return self(z, **kwargs)
 
     def p_losses(self, x_start, t, *args, noise: Optional[torch.Tensor] = None, **kwargs):
@@ -115,11 +117,12 @@ class LatentDiffusion(DDPM):
         x_start = x_start.to(torch.float32).contiguous()
         t = t.to(torch.float32).contiguous()
         x_noisy = self.q_sample(x_start, noise, t)
-        C_pred, noise_pred = self.model(x_noisy, t, **kwargs)
+        C_pred, noise_pred = self.model(x_noisy, t, *args, **kwargs)
         w1, w2 = self.loss_weights(t)
         W = (-torch.log(t) / 2).sum()
         w = torch.stack([w1, w2, W.expand_as(w1)], dim=1).contiguous()
-        loss, per_simple, per_l1 = ops.ddm_loss_latent(C_pred, noise_pred, x_start, noise, x_noisy, t, w)
+        loss, per_simple, per_l1 = ops.ddm_loss_latent(C_pred, noise_pred, x_start, noise, x_noisy, t, w, self._sched,
+                                                       self.use_l1)
         B, n = x_start.shape[0], x_start[0].numel()
         loss_vlb = per_l1.sum() * W
         log = {"train/loss_simple": per_simple.sum() / B / n,
@@ -130,15 +133,17 @@ class LatentDiffusion(DDPM):
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()
     def sample(self, batch_size=16, up_scale=1, cond=None, mask=None, denoise=True, x_T=None, epsilons=None):
-        if cond is not None or mask is not None:
-            raise NotImplementedError("conditional / masked sampling is not on the unconditional hot path")
+        if mask is not None:
+            raise NotImplementedError("masked (in-painting) sampling is not implemented")
+        if cond is not None:       # ddm_const_2.py:599-601: the condition sets the batch size
+            batch_size = cond[0].shape[0] if isinstance(cond, (list, tuple)) else cond.shape[0]
         down = self.first_stage_model.down_ratio
         shape = (batch_size, self.channels, self.image_size[0] // down, self.image_size[1] // down)
         sample_type = _cfg_get(self.cfg, "sample_type", "deterministic")
         if sample_type == "deterministic":
-            z = self.sample_fn_d(shape, unnormalize=False, x_T=x_T)
+            z = self.sample_fn_d(shape, unnormalize=False, x_T=x_T, cond=cond)
         elif sample_type == "stochastic":
-            z = self.sample_fn_s(shape, unnormalize=False, denoise=denoise, x_T=x_T, epsilons=epsilons)
+            z = self.sample_fn_s(shape, unnormalize=False, denoise=denoise, x_T=x_T, epsilons=epsilons, cond=cond)
         else:
             raise NotImplementedError(sample_type)
         if self.scale_by_std:
@@ -169,7 +174,7 @@ class LatentDiffusion(DDPM):
                 s = cur
             t_vec = torch.full((B,), cur, dtype=torch.float64, device=dev)
             s_vec = torch.full((B,), s, dtype=torch.float64, device=dev)
-            C, noise = self.model(img, t_vec)
+            C, noise = self.model(img, t_vec, cond) if cond is not None else self.model(img, t_vec)
             z = (epsilons[k].to(device=dev, dtype=torch.float64) if epsilons is not None
                  else torch.randn(shape, device=dev, dtype=torch.float64)).contiguous()
             # scale_by_softsign: the predicted x0 is clamped to +-0.987654321 before C is re-derived (ddm_const_2.py:661-665)

@@ -38,6 +38,8 @@ class DDPMBase(nn.Module):
     DEFAULT_EPS = 1e-4
     USES_LPIPS = True           # the pixel-space p_losses has the LPIPS term; LatentDiffusion's does not
     AUGMENT_P = 0.15            # AugmentPipe probability multiplier: 0.15 in ddm_const.py:179, 0.12 in ddm_const_2.py:112
+    SUPPORTS_L1 = False         # use_l1 (L1 twins of the SSE terms) exists in the latent p_losses only (ddm_const_2.py:556-559)
+    CLIP_IN_SAMPLER = True      # pixel-space 'const' sampler clamps the predicted x0 (ddm_const.py:453-454); latent ones never do
 
     def __init__(self, model, *, image_size, sampling_timesteps=None, loss_type="l2", objective="pred_noise",
                  beta_schedule="cosine", clip_x_start=True, input_keys=("image",), start_dist="normal",
@@ -65,8 +67,8 @@ class DDPMBase(nn.Module):
         self.start_dist = start_dist
         self.loss_type = loss_type
         self.sampling_timesteps = 10 if sampling_timesteps is None else sampling_timesteps
-        if use_l1:
-            raise NotImplementedError("use_l1 is False in every DDM config; not implemented")
+        if use_l1 and not self.SUPPORTS_L1:
+            raise NotImplementedError("use_l1 is implemented for the latent wrappers only (no pixel-space DDM config sets it)")
         self.use_l1 = use_l1
         self.perceptual_weight = perceptual_weight
         if perceptual_weight > 0 and self.USES_LPIPS:
@@ -242,10 +244,10 @@ class DDPMBase(nn.Module):
         if x_T is None:
             x_T = self._start_noise(shape, dev)
         x = (x_T.to(device=dev, dtype=torch.float64) * float(ts[0])).contiguous()
-        clip = self.clip_x_start and self.SCHEDULE == "const"     # const_2's deterministic sampler never clamps x0
+        clip = self.clip_x_start and self.SCHEDULE == "const" and self.CLIP_IN_SAMPLER     # const_2 / latent: never clamps x0
         traj = []
         n = len(ts) - 1
-        g = self._sampling_graph(tuple(shape), dev) if self._use_graph() else None
+        g = self._sampling_graph(tuple(shape), dev) if (self._use_graph() and cond is None) else None
         if g is not None:           # the UNet forward replays from a captured HIP graph on static buffers
             g["x"].copy_(x)
             x = g["x"]
@@ -255,6 +257,8 @@ class DDPMBase(nn.Module):
                 g["t"].fill_(t_cur)
                 g["graph"].replay()
                 C, noise = g["C"], g["noise"]
+            elif cond is not None:     # conditional denoiser: model(x, t, cond)  (ddm_const_2.py:712-715)
+                C, noise = self.model(x, torch.tensor(t_cur, dtype=torch.float64, device=dev), cond)
             else:
                 C, noise = self.model(x, torch.tensor(t_cur, dtype=torch.float64, device=dev))
             last = unnormalize and i == n - 1

@@ -65,11 +65,34 @@ _SIGS = {
     "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, P, I, I, I, P],
     "adm_q_sample": [P, P, P, P, I, L, I, P],
     "adm_ddm_loss": [P, P, P, P, P, P, P, P, F, I, L, P],
-    "adm_ddm_loss_latent": [P, P, P, P, P, P, P, P, P, P, P, F, I, L, P],
+    "adm_ddm_loss_latent": [P, P, P, P, P, P, P, P, P, P, P, F, I, L, I, I, P],
     "adm_sampler_step": [P, P, P, D, D, I, I, D, I, L, P],
     "adm_sampler_step_stochastic": [P, P, P, P, P, P, I, I, D, I, I, L, P],
     "adm_aug_workspace_floats": [I, I, I, I],
     "adm_augment_geometric": [P, P, P, P, P, P, I, I, I, I, P],
+    "adm_conv_wgrad_strided": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_pack_weight_tconv": [P, P, I, I, I, I, I, P],
+    "adm_col2im": [P, P, I, I, I, I, I, I, I, I, I, P],
+    "adm_ws_fwd": [P, P, P, I, I, F, P],
+    "adm_ws_bwd": [P, P, P, P, I, I, I, P],
+    "adm_lnc_blocks": [L],
+    "adm_lnc_fwd": [P, P, P, L, I, F, P],
+    "adm_lnc_bwd": [P, P, P, P, P, P, L, I, F, I, P],
+    "adm_bn_blocks": [L],
+    "adm_bn_fwd": [P, P, P, P, P, P, P, P, L, I, F, F, I, P],
+    "adm_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "adm_bilinear_fwd": [P, P, I, I, I, I, I, I, I, I, I, P],
+    "adm_bilinear_bwd": [P, P, I, I, I, I, I, I, I, I, I, P],
+    "adm_act_fwd": [P, P, L, I, F, U, P],
+    "adm_act_bwd": [P, P, P, L, I, F, U, P],
+    "adm_fourier_features": [P, P, P, I, I, P],
+    "adm_spatial_att_big_fwd": [P, I, P, P, P, P, P, I, I, I, P],
+    "adm_spatial_att_big_bwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, P],
+    "adm_mha_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P],
+    "adm_mha_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, P],
+    "adm_linattn_ws_floats": [I, I],
+    "adm_linattn_fwd": [P, P, P, P, P, I, I, P],
+    "adm_linattn_bwd": [P, P, P, P, P, P, P, P, I, I, P],
     "adm_sumsq_blocks": [L],
     "adm_sumsq": [P, P, P, L, P],
     "adm_adamw_step": [P, P, P, P, P, P, L, F, F, F, F, F, F, I, F, F, P],
@@ -97,7 +120,7 @@ def lib() -> ctypes.CDLL:
         for name, args in _SIGS.items():
             fn = getattr(_lib, name)      # AttributeError if the .so lacks a declared symbol
             fn.argtypes = args
-            fn.restype = c_long if name == "adm_aug_workspace_floats" else c_int
+            fn.restype = c_long if name in ("adm_aug_workspace_floats", "adm_linattn_ws_floats") else c_int
     return _lib
 
 
@@ -110,7 +133,7 @@ def ptr(t) -> c_void_p:
 
 
 NO_STREAM = ("adm_version", "adm_conv_splitk", "adm_gn_splits", "adm_aug_workspace_floats", "adm_conv_wgrad_plan",
-             "adm_sumsq_blocks")      # host-side queries: no stream argument, called as lib().name(...)
+             "adm_sumsq_blocks", "adm_lnc_blocks", "adm_bn_blocks", "adm_linattn_ws_floats")      # host-side queries: no stream argument, called as lib().name(...)
 
 
 def call(name: str, *args):

@@ -874,14 +874,14 @@ class _DdmLossLatent(torch.autograd.Function):
     (sum_b simple_b / B, per-sample simple, per-sample un-weighted L1)."""
 
     @staticmethod
-    def forward(ctx, c_pred, n_pred, x0, noise, xt, t, w):
+    def forward(ctx, c_pred, n_pred, x0, noise, xt, t, w, schedule, use_l1):
         c_pred, n_pred = _chk(c_pred, "C_pred"), _chk(n_pred, "noise_pred")
         B = c_pred.shape[0]
         n = c_pred.numel() // B
         per, l1 = _new((B,), c_pred), _new((B,), c_pred)
         dc, dn = torch.empty_like(c_pred), torch.empty_like(n_pred)
         call("adm_ddm_loss_latent", ptr(c_pred), ptr(n_pred), ptr(x0), ptr(noise), ptr(xt), ptr(t), ptr(w), ptr(per),
-             ptr(l1), ptr(dc), ptr(dn), 1.0 / B, B, n)
+             ptr(l1), ptr(dc), ptr(dn), 1.0 / B, B, n, int(schedule), int(use_l1))
         ctx.save_for_backward(dc, dn)
         ctx.mark_non_differentiable(per, l1)
         return (per.sum() + (l1 * w[:, 2]).sum()) / B, per, l1
@@ -889,12 +889,14 @@ class _DdmLossLatent(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gper, _gl1):
         dc, dn = ctx.saved_tensors
-        return dc * gloss, dn * gloss, None, None, None, None, None
+        return dc * gloss, dn * gloss, None, None, None, None, None, None, None
 
 
-def ddm_loss_latent(c_pred, n_pred, x0, noise, xt, t, w):
+def ddm_loss_latent(c_pred, n_pred, x0, noise, xt, t, w, schedule: int = 1, use_l1: bool = False):
+    """schedule 0 = 'const' (x_rec uses sqrt(t) eps), 1 = 'const_2' (t eps); use_l1 adds the L1 twins of both SSE terms and
+    halves the sum (ddm_const_2.py:556-559)."""
     return _DdmLossLatent.apply(c_pred, n_pred, _chk(x0, "x0"), _chk(noise, "noise"), _chk(xt, "x_t"), _chk(t, "t"),
-                                _chk(w, "weights"))
+                                _chk(w, "weights"), int(schedule), bool(use_l1))
 
 
 def sampler_step(x64, c_pred, n_pred, t_cur: float, t_next: float, schedule: int, clip_x0: bool, scale_input: float,

@@ -168,7 +168,8 @@ def _decouple(seq: nn.Sequential, x):
     h = ops.conv2d(x, conv.weight, conv.bias)
     att = ops.conv2d(h, sa.map.weight, sa.map.bias)
     qk = torch.cat([sa.q_conv.weight.reshape(1), sa.q_conv.bias, sa.k_conv.weight.reshape(1), sa.k_conv.bias])
-    return ops.spatial_att_gate(att, qk, h, x)
+    from .. import ops_cond            # maps larger than 8x8 (a bottleneck above 4x4) take the recomputing kernel
+    return ops_cond.spatial_att_gate(att, qk, h, x)
 
 
 class DhariwalUNet(nn.Module):

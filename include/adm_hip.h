@@ -256,7 +256,8 @@ int adm_ddm_loss(const float* c_pred, const float* n_pred, const float* x0, cons
  * dNp = gscale (2 w2 (Np - noise) - w3 t sign(x_rec - x0)).  Both outputs are zero-filled by the call. */
 int adm_ddm_loss_latent(const float* c_pred, const float* n_pred, const float* x0, const float* noise, const float* xt,
                         const float* t, const float* w, float* per_sample, float* per_l1, float* d_c, float* d_n,
-                        float gscale, int B, long n, hipStream_t stream);
+                        float gscale, int B, long n, int schedule, int use_l1,
+                        hipStream_t stream);
 /* One deterministic sampler update in fp64 (ddm_const.py:450-455 / ddm_const_2.py:363-368):
  * x0 = x - C t - eps g(t); [clamp]; x_next = x0 + C t' + eps g(t');  if last: clamp, /scale, (x+1)/2 */
 int adm_sampler_step(double* x, const float* c_pred, const float* n_pred, double t_cur, double t_next, int schedule,
@@ -293,6 +294,81 @@ int adm_sumsq(const float* g, double* sumsq, double* partials, long n, hipStream
 int adm_adamw_step(float* p, const float* g, float* m, float* v, float* ema, const double* sumsq, long n, float lr,
                    float beta1, float beta2, float eps, float wd, float max_norm, int step, float ema_decay,
                    float grad_scale, hipStream_t stream);
+
+
+/* ================================================================================================
+ * Conditional super-resolution denoiser (BASELINE configs[4]):
+ * the operators /root/reference/unet/cond_unet_sd.py needs beyond the unconditional UNet's.  NHWC fp32.
+ * ================================================================================================ */
+
+/* adm_conv_wgrad for a strided conv with explicit top/left padding (Downsample = Conv2d(C, C', 4, 2, 1), cond_unet_sd.py:341-342;
+ * also the 7x7 stem with stride 1, pad_lo 3): tap (ky, kx) of output (oy, ox) reads x(oy*stride + ky - pad_lo, ...).  The forward
+ * is adm_conv_fwd_strided (ks up to 7). */
+int adm_conv_wgrad_strided(const float* x, const float* dy, float* dwp, float* dbias, int B, int Hin, int Win, int Hout, int Wout,
+                           int Cin, int ldx, int Cout, int lddy, int ks, int stride, int pad_lo, hipStream_t stream);
+/* B operand of the GEMM form of the transposed conv (data gradient of a strided conv): out[(tap*Ci_pad + ci)][co] = w[co][ci][tap];
+ * col[m][(tap, ci)] = adm_conv_fwd(dy as a 1x1 conv with this operand), then adm_col2im gathers dx. */
+int adm_pack_weight_tconv(const float* w, float* out, int Co, int Ci, int ks, int Co_pad, int Ci_pad, hipStream_t stream);
+int adm_col2im(const float* col, float* dx, int B, int Hin, int Win, int Ho, int Wo, int C, int ks, int stride, int pad_lo,
+               hipStream_t stream);
+
+/* WeightStandardizedConv2d (cond_unet_sd.py:344-357): wn[o][:] = (w[o][:] - mean_o) * rsqrt(var_o + eps) over the K = Cin*kh*kw
+ * values of output channel o; stats[o] = (mean, rstd).  Backward: dw (+)= rstd (dwn - mean(dwn) - wn mean(dwn wn)). */
+int adm_ws_fwd(const float* w, float* wn, float* stats, int O, int K, float eps, hipStream_t stream);
+int adm_ws_bwd(const float* w, const float* stats, const float* dwn, float* dw, int O, int K, int accumulate, hipStream_t stream);
+
+/* LayerNorm over the channels of every pixel with gain g and no bias (cond_unet_sd.py:359-368): x, y [M][C]. */
+int adm_lnc_blocks(long M);
+int adm_lnc_fwd(const float* x, const float* g, float* y, long M, int C, float eps, hipStream_t stream);
+/* part = workspace of adm_lnc_blocks(M) * C doubles */
+int adm_lnc_bwd(const float* x, const float* dy, const float* g, float* dx, float* dg, double* part, long M, int C, float eps,
+                int accumulate, hipStream_t stream);
+
+/* nn.BatchNorm2d of RelationNet.input_conv{1,2} (cond_unet_sd.py:247-254) on [M][C] rows.  training: batch statistics, running
+ * statistics updated in place (momentum, unbiased variance), mr[c] = (mean, rstd) saved for the backward; else mr from the running
+ * statistics.  part = adm_bn_blocks(M) * 2 C doubles; sums = 2 C floats. */
+int adm_bn_blocks(long M);
+int adm_bn_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mr, float* y,
+               double* part, long M, int C, float eps, float momentum, int training, hipStream_t stream);
+int adm_bn_bwd(const float* x, const float* dy, const float* mr, const float* gamma, float* dx, float* dgamma, float* dbeta,
+               double* part, float* sums, long M, int C, int training, int accumulate, hipStream_t stream);
+
+/* F.interpolate(mode='bilinear', align_corners=...) (cond_unet_sd.py:196, 235, 824): x [B][Hi][Wi][C] -> channels
+ * [coff, coff + C) of y [B][Ho][Wo][ldy]; the backward is the exact adjoint in gather form (no atomics). */
+int adm_bilinear_fwd(const float* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int ldy, int coff, int align_corners,
+                     hipStream_t stream);
+int adm_bilinear_bwd(const float* dy, float* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int lddy, int coff,
+                     int align_corners, hipStream_t stream);
+
+/* act: 0 identity, 1 ReLU, 2 GELU (erf form), followed by dropout(p) with the stateless hash of the GroupNorm kernels. */
+int adm_act_fwd(const float* x, float* y, long n, int act, float drop_p, uint64_t seed, hipStream_t stream);
+int adm_act_bwd(const float* x, const float* dy, float* dx, long n, int act, float drop_p, uint64_t seed, hipStream_t stream);
+/* GaussianFourierProjection (cond_unet_sd.py:396-405): out[b] = [sin(2 pi x_b W), cos(2 pi x_b W)], W [D] */
+int adm_fourier_features(const float* x, const float* W, float* out, int B, int D, hipStream_t stream);
+
+/* adm_spatial_att_fwd / _bwd for maps of up to 2560 pixels (the 16x16 bottleneck of the SR denoiser): nothing of the HW x HW
+ * softmax is stored; gate [B][HW][2] carries (pooled value, log-sum-exp) per row to the backward. */
+int adm_spatial_att_big_fwd(const float* att, int ldatt, const float* qk, const float* h, const float* xres, float* y, float* gate,
+                            int B, int HW, int C, hipStream_t stream);
+int adm_spatial_att_big_bwd(const float* att, int ldatt, const float* qk, const float* h, const float* dy, const float* gate,
+                            float* dh, float* datt, float* dqk, float* dqk_part, int B, int HW, int C, hipStream_t stream);
+
+/* softmax(scale q k^T) v per (image, head) with separate query / key lengths; head h = columns [h*D, (h+1)*D) of rows with
+ * strides ldq / ldk / ldv / ldo; D in {4, 8, 16, 32, 64}.  RelationNet's windowed cross-attention (cond_unet_sd.py:221-231,
+ * scale 1) and the bottleneck Attention (:532-554, scale 32^-0.5).  lse [B*H][Lq]; delta = workspace [B*H][Lq]. */
+int adm_mha_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int Lq, int Lk, int H, int D, int ldq,
+                int ldk, int ldv, int ldo, float scale, hipStream_t stream);
+int adm_mha_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse, float* dq,
+                float* dk, float* dv, float* delta, int B, int Lq, int Lk, int H, int D, int ldq, int ldk, int ldv, int ldo, int lddq,
+                int lddk, int lddv, float scale, hipStream_t stream);
+
+/* LinearAttention core (cond_unet_sd.py:516-529): qkv [B][N][384] = (q | k | v) of 4 heads x 32 -> out [B][N][128];
+ * ctx [B][4][32][32] and kst [B][128][2] are saved for the backward; ws = adm_linattn_ws_floats(B, N) floats;
+ * dctx [B][4][32][32] and S [B][128] are workspaces of the backward. */
+long adm_linattn_ws_floats(int B, int N);
+int adm_linattn_fwd(const float* qkv, float* out, float* ctx, float* kst, float* ws, int B, int N, hipStream_t stream);
+int adm_linattn_bwd(const float* qkv, const float* dout, const float* ctx, const float* kst, float* dqkv, float* dctx, float* S,
+                    float* ws, int B, int N, hipStream_t stream);
 
 #ifdef __cplusplus
 }
