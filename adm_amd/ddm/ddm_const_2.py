@@ -132,13 +132,15 @@ class LatentDiffusion(DDPM):
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()
-    def sample(self, batch_size=16, up_scale=1, cond=None, mask=None, denoise=True, x_T=None, epsilons=None):
+    def sample(self, batch_size=16, up_scale=1, cond=None, mask=None, denoise=True, x_T=None, epsilons=None, latent_hw=None):
         if mask is not None:
             raise NotImplementedError("masked (in-painting) sampling is not implemented")
         if cond is not None:       # ddm_const_2.py:599-601: the condition sets the batch size
             batch_size = cond[0].shape[0] if isinstance(cond, (list, tuple)) else cond.shape[0]
         down = self.first_stage_model.down_ratio
         shape = (batch_size, self.channels, self.image_size[0] // down, self.image_size[1] // down)
+        if latent_hw is not None:      # sliding-window SR: a border window smaller than the configured image (sample_cond_ldm.py)
+            shape = (batch_size, self.channels, int(latent_hw[0]), int(latent_hw[1]))
         sample_type = _cfg_get(self.cfg, "sample_type", "deterministic")
         if sample_type == "deterministic":
             z = self.sample_fn_d(shape, unnormalize=False, x_T=x_T, cond=cond)

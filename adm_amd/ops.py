@@ -147,9 +147,12 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
         call("adm_permute_vec", ptr(b), ptr(ent.bias), co, cop, int(qkv), 0)
     try:
         weight._adm_packed = ent
-        _pack_registry[id(weight)] = (weakref.ref(weight), None if bias is None else weakref.ref(bias), ks, qkv)
-        global _pack_table
-        _pack_table = None
+        # only PARAMETERS join the one-launch repack table: a derived weight (weight standardisation: a fresh tensor per step)
+        # would only churn it
+        if isinstance(weight, torch.nn.Parameter):
+            _pack_registry[id(weight)] = (weakref.ref(weight), None if bias is None else weakref.ref(bias), ks, qkv)
+            global _pack_table
+            _pack_table = None
     except (AttributeError, TypeError):
         pass
     return ent

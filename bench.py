@@ -52,11 +52,14 @@ def parse():
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="run warmup+steps only (for rocprofv3)")
     ap.add_argument("--small", action="store_true", help="reduced-width model (debug only; result marked invalid)")
-    ap.add_argument("--config", choices=["cifar", "latent", "latent-ae"], default="cifar",
+    ap.add_argument("--config", choices=["cifar", "latent", "latent-ae", "sr"], default="cifar",
                     help="cifar = BASELINE configs[1] (default, the headline metric); latent = the UNet of configs[3] alone "
                          "(uncond_unet_sd_2 on 64x64x3 latents, model_channels 128; default --batch 32); latent-ae = all of "
                          "configs[3]: 256x256 images -> frozen KL-f4 autoencoder encode -> LatentDiffusion step; sampling "
-                         "ends with the decode to 256x256")
+                         "ends with the decode to 256x256; sr = BASELINE configs[4]: DIV2K 4x super-resolution, 512x512 images -> "
+                         "frozen KL-f4 encode -> conditional LatentDiffusion (ddm_const, use_l1) on 128x128x3 latents with "
+                         "unet.cond_unet_sd.Unet (dim 128) and INJECTED condition-encoder features (the Swin-B backbone is not "
+                         "part of this build); sample = 5-step latent sampler + decode to 512x512; default --batch 16")
     ap.add_argument("--augment", action="store_true",
                     help="use_augment: True as in the reference's CIFAR YAML: AugmentPipe on x_start + 9 augment labels "
                          "(SURVEY 8d asks for this as a second number; the headline line keeps it off)")
@@ -66,7 +69,32 @@ def parse():
     return ap.parse_args()
 
 
+def build_sr_model(dev, small=False):
+    """configs/super-resolution/div2k_cond_ddm_const_ldm.yaml: KL-f4 first stage (ch 128) + cond_unet_sd.Unet(dim 128)."""
+    import warnings
+    from adm_amd.ddm.ddm_const import LatentDiffusion
+    from adm_amd.ddm.encoder_decoder import AutoencoderKL
+    from adm_amd.unet.cond_unet_sd import Unet
+    torch.manual_seed(1234)
+    dim = 32 if small else 128
+    dd = dict(double_z=True, z_channels=3, resolution=[512, 512], in_channels=3, out_ch=3, ch=32 if small else 128, ch_mult=[1, 2, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    ae = AutoencoderKL(dd, dict(disc_start=50001, kl_weight=1e-6, disc_weight=0.5), 3)
+    unet = Unet(dim=dim, dim_mults=(1, 2, 4, 4), cond_dim=dim, cond_dim_mults=(), channels=3, cond_in_dim=3,
+                window_sizes1=[[8, 8], [4, 4], [2, 2], [1, 1]], window_sizes2=[[4, 4], [2, 2], [1, 1], [1, 1]], fourier_scale=16,
+                cfg={"cond_net": "swin", "cond_pe": False})
+    mcfg = dict(eps=1e-4, sigma_max=1, sigma_min=0.01, weighting_loss=True, use_augment=False, ldm=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dpm = LatentDiffusion(auto_encoder=ae, scale_factor=0.195, scale_by_std=True, default_scale=True, model=unet,
+                              image_size=[512, 512], sampling_timesteps=5, loss_type="l2", start_dist="normal",
+                              perceptual_weight=0.0, use_l1=True, cfg=mcfg)
+    return dpm.to(dev)
+
+
 def build_model(dev, small=False, config="cifar", augment=False):
+    if config == "sr":
+        return build_sr_model(dev, small)
     from adm_amd.ddm.ddm_const import DDPM
     from adm_amd.unet.uncond_unet import EDMPrecond
     kw = dict(model_channels=192, channel_mult=[1, 2, 2, 2], channel_mult_emb=4, num_blocks=3, attn_resolutions=[16, 8],
@@ -183,10 +211,13 @@ def main():
     reducer = BucketedGradReducer(flat, force=force_dist)
     log(f"world={world} rank={rank} buckets={len(reducer.buckets)} reducer_active={reducer.active}")
     opt = FusedAdamWEMA(flat, lr=1e-4, weight_decay=1e-4, max_norm=1.0, ema=(rank == 0))
-    B = args.batch if (args.config == "cifar" or args.batch != 128) else 32
-    R = {"cifar": 32, "latent": 64, "latent-ae": 256}[args.config]
+    B = args.batch if (args.config == "cifar" or args.batch != 128) else (16 if args.config == "sr" else 32)
+    R = {"cifar": 32, "latent": 64, "latent-ae": 256, "sr": 512}[args.config]
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
     batches = [{"image": torch.rand(B, 3, R, R, device=dev, generator=gen) * 2 - 1} for _ in range(2)]
+    if args.config == "sr":       # the condition encoder's outputs for a 128x128 low-resolution image (Swin-B geometry), synthetic
+        for bt in batches:
+            bt["cond"] = [torch.randn(B, 128 << i, 32 >> i, 32 >> i, device=dev, generator=gen) for i in range(4)]
 
     def train_step(it):
         flat.zero_grad()
@@ -334,23 +365,25 @@ def main():
     # ---- 10-step sampling, every rank samples its own batch, no collectives ----
     if not args.no_sample:
         dpm.eval()
-        dpm.sample(batch_size=min(B, 16))
+        skw = {"cond": batches[0]["cond"]} if args.config == "sr" else {}
+        dpm.sample(batch_size=min(B, 16), **({"cond": [c[:min(B, 16)] for c in skw["cond"]]} if skw else {}))
         barrier()
         t0 = time.perf_counter()
-        img = dpm.sample(batch_size=B)
+        img = dpm.sample(batch_size=B, **skw)
         barrier()
         st = time.perf_counter() - t0
         if use_dist:
             tmax = torch.tensor([st], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             st = float(tmax)
-        assert img.shape == (B, 3, R, R) and img.dtype == (torch.float32 if args.config == "latent-ae" else torch.float64)
+        assert img.shape == (B, 3, R, R) and img.dtype == (torch.float32 if args.config in ("latent-ae", "sr") else torch.float64)
         sample_ips = world * B / st
         log(f"sample({B}) took {st:.3f}s")
 
     if rank == 0:
         what = {"cifar": "CIFAR-10 32x32 uncond DDM UNet", "latent": "64x64x3-latent uncond DDM UNet (configs[3], UNet only)",
-                "latent-ae": "CelebA-HQ-256-shaped latent DDM: frozen KL-f4 AE + 64x64x3-latent UNet (configs[3])"}[args.config]
+                "latent-ae": "CelebA-HQ-256-shaped latent DDM: frozen KL-f4 AE + 64x64x3-latent UNet (configs[3])",
+                "sr": "DIV2K 4x SR: frozen KL-f4 AE + conditional cond_unet_sd on 128x128x3 latents (configs[4])"}[args.config]
         out = {"metric": f"train images/sec ({what}, 1 optimizer step/iter) + 10-step sample images/sec",
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -361,12 +394,16 @@ def main():
                                        else "BASELINE configs[3]: 256x256 images -> frozen KL-f4 AutoencoderKL.encode (55M params, no "
                                        "grad) -> LatentDiffusion (ddm_const_2, uncond_unet_sd_2 model_channels 128) training step; "
                                        "sample = 10-step latent sampler + AutoencoderKL.decode to 256x256: " if args.config == "latent-ae"
+                                       else "BASELINE configs[4] (per-GPU share): 512x512 images -> frozen KL-f4 AutoencoderKL.encode -> conditional "
+                                       "LatentDiffusion (ddm_const, use_l1) with unet.cond_unet_sd.Unet (dim 128, 87M params) on 128x128x3 "
+                                       "latents; condition = INJECTED synthetic Swin-B-shaped feature pyramid (the backbone is not part of this "
+                                       "build); sample = 5-step latent sampler + decode to 512x512: " if args.config == "sr"
                                        else ("BASELINE configs[1]" if args.dtype == "f32" else "BASELINE configs[2] (per-GPU share)") +
                                        ": CIFAR-10 32x32 uncond two-decoder DhariwalUNet (216M params), ") +
-                                      f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, {'ddm_const' if args.config == 'cifar' else 'ddm_const_2'} schedule, dropout 0.1, " +
-                                      ("loss_simple + latent L1 term" if args.config == "latent-ae" else "loss_simple (LPIPS term needs unfetchable VGG16 weights)") +
+                                      f"bs={B}/GPU {'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands, fp32 accumulate+storage'}, {'ddm_const' if args.config in ('cifar', 'sr') else 'ddm_const_2'} schedule, dropout 0.1, " +
+                                      ("loss_simple + latent L1 term" if args.config in ("latent-ae", "sr") else "loss_simple (LPIPS term needs unfetchable VGG16 weights)") +
                                       ", clip 1.0 + AdamW + EMA(every 8)" + (", use_augment (AugmentPipe p=0.15 + labels)" if args.augment else ""),
-                          "global_batch": world * B, "image": f"3x{R}x{R}", "sampling_timesteps": 10,
+                          "global_batch": world * B, "image": f"3x{R}x{R}", "sampling_timesteps": 5 if args.config == "sr" else 10,
                           "parallelism": f"dp{world}", "valid": not args.small},
                "final_loss": round(final_loss, 4), "roofline": roof,
                "dist": {"backend": (dist.get_backend() if use_dist else None),

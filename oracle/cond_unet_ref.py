@@ -395,3 +395,43 @@ def cond_features(B, H, W, f=128, tag="hm"):
     """Deterministic stand-ins for the Swin-B feature pyramid of a condition image of size H x W (inputs of the tests)."""
     from . import fill
     return [fill.hash_tensor((B, f * 2 ** i, max(H // (4 << i), 1), max(W // (4 << i), 1)), f"{tag}{i}", 1.0) for i in range(4)]
+
+
+# ------------------------------------------------------------------------------------------------ conditional latent wrapper
+def latent_p_losses_const(model_fn, x_start, t, noise, eps=1e-4, weighting_loss=True, use_l1=True):
+    """ddm_const_2.LatentDiffusion.p_losses (ddm_const_2.py:527-596) evaluated with the 'const' (sqrt t) schedule of
+    ddm_const.py:284-293, 336-338 -- the upstream-shaped latent wrapper the DIV2K recipe names (its fork rewrite needs
+    pytorch_lightning and cannot be imported: restated from the two texts, NOT pinned by import).  model_fn(x_t, t) ->
+    (C_pred, noise_pred).  Keeps the reference's [B] x [B, 1] broadcast of rec_weight (:566-568)."""
+    B = x_start.shape[0]
+    tt = t.reshape(B, 1, 1, 1)
+    C = -x_start
+    x_noisy = x_start + C * tt + tt.sqrt() * noise
+    C_pred, noise_pred = model_fn(x_noisy, t)
+    x_rec = x_noisy - C_pred * tt - tt.sqrt() * noise_pred
+    if weighting_loss:
+        w1, w2 = (t ** 2 - t + 1) / t, (t ** 2 - t + 1) / (1 - t + eps)
+    else:
+        w1 = w2 = torch.ones_like(t)
+    sse = lambda a, b: ((a - b) ** 2).sum([1, 2, 3])
+    loss_simple = w1 * sse(C_pred, C) + w2 * sse(noise_pred, noise)
+    if use_l1:
+        loss_simple = (loss_simple + w1 * (C_pred - C).abs().sum([1, 2, 3]) + w2 * (noise_pred - noise).abs().sum([1, 2, 3])) / 2
+    rec_weight = -torch.log(t.reshape(B, 1)) / 2
+    loss_vlb = (x_rec - x_start).abs().sum([1, 2, 3]) * rec_weight          # [B, B]: the reference's broadcast
+    loss = loss_simple.sum() / B + loss_vlb.sum() / B
+    n = x_start[0].numel()
+    return loss, {"train/loss_simple": loss_simple.detach().sum() / B / n, "train/loss_vlb": loss_vlb.detach().sum() / B / n}
+
+
+def latent_sample_fn_d_const(model_fn, x_T, n, sigma_min=0.01, sigma_max=1.0):
+    """The fork's latent deterministic sampler (ddm_const.py:868-889): t_i = sigma_max + i/(n-1) (sigma_min^2 - sigma_max), then
+    0; x += (t' - t)(C + eps / (sqrt t + sqrt t')); fp64 state, no clamps, no un-normalisation."""
+    i = torch.arange(n, dtype=torch.float64)
+    ts = torch.cat([sigma_max + i / (n - 1) * (sigma_min ** 2 - sigma_max), torch.zeros(1, dtype=torch.float64)])
+    x = x_T.to(torch.float64) * ts[0]
+    for t_cur, t_next in zip(ts[:-1], ts[1:]):
+        C, noise = model_fn(x, t_cur)
+        C, noise = C.to(torch.float64), noise.to(torch.float64)
+        x = x + (t_next - t_cur) * (C + noise / (t_cur.sqrt() + t_next.sqrt()))
+    return x
