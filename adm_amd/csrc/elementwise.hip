@@ -494,6 +494,40 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   }
 }
 
+// Rows longer than the register budget (the 512x512 autoencoder of the SR recipe: 128 x 128 = 16384 tokens): three passes
+// over the row (max, sum of exponentials, write); a 64 KiB row stays in the L2 between them.
+__global__ __launch_bounds__(256) void softmax_rows_long_kernel(float* __restrict__ s, int cols, long ld, float scale) {
+  __shared__ float red[4];
+  float* row = s + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x, nv = cols >> 2;
+  float mx = -INFINITY;
+  for (int q = tid; q < nv; q += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * q) * scale;
+    mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int q = tid; q < nv; q += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * q) * scale;
+    sum += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int q = tid; q < nv; q += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * q) * scale;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __expf(v[j] - mx) * inv;
+    *reinterpret_cast<f32x4*>(row + 4 * q) = v;
+  }
+}
+
 // z = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps  over NHWC moments [M][ldm] = (mean[0:C] | logvar[C:2C])
 // (DiagonalGaussianDistribution.sample, /root/reference/ddm/encoder_decoder.py:855-867); eps NULL -> the mode.
 __global__ void posterior_sample_kernel(const float* __restrict__ mom, int ldm, const float* __restrict__ eps,
@@ -514,9 +548,10 @@ __global__ void posterior_sample_kernel(const float* __restrict__ mom, int ldm, 
 }  // namespace
 
 extern "C" int adm_softmax_rows(float* s, long rows, int cols, long ld, float scale, hipStream_t stream) {
-  if (!s || rows <= 0 || rows >= (1L << 31) || cols <= 0 || (cols & 3) || cols > 8192 || ld < cols || (ld & 3)) return ADM_EINVAL;
+  if (!s || rows <= 0 || rows >= (1L << 31) || cols <= 0 || (cols & 3) || cols > (1 << 20) || ld < cols || (ld & 3)) return ADM_EINVAL;
   if ((uintptr_t)s & 15) return ADM_EINVAL;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, s, cols, ld, scale);
+  if (cols > 8192) hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(256), 0, stream, s, cols, ld, scale);
+  else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, s, cols, ld, scale);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

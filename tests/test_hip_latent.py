@@ -59,7 +59,7 @@ def test_strided_conv_is_forward_only(gpu):
         ops.conv2d_strided(torch.zeros(1, 8, 8, 32, device=gpu), w, None)
 
 
-@pytest.mark.parametrize("rows,cols", [(64, 64), (300, 1024), (5, 4096), (17, 8192), (9, 36)])
+@pytest.mark.parametrize("rows,cols", [(64, 64), (300, 1024), (5, 4096), (17, 8192), (9, 36), (7, 16384), (3, 8196)])   # > 8192: the three-pass kernel
 def test_softmax_rows_vs_torch(gpu, rows, cols):
     from adm_amd import ops
     s = fill.hash_tensor((rows, cols), "sm", 6.0)
