@@ -384,7 +384,7 @@ def main():
         what = {"cifar": "CIFAR-10 32x32 uncond DDM UNet", "latent": "64x64x3-latent uncond DDM UNet (configs[3], UNet only)",
                 "latent-ae": "CelebA-HQ-256-shaped latent DDM: frozen KL-f4 AE + 64x64x3-latent UNet (configs[3])",
                 "sr": "DIV2K 4x SR: frozen KL-f4 AE + conditional cond_unet_sd on 128x128x3 latents (configs[4])"}[args.config]
-        out = {"metric": f"train images/sec ({what}, 1 optimizer step/iter) + 10-step sample images/sec",
+        out = {"metric": f"train images/sec ({what}, 1 optimizer step/iter) + {5 if args.config == 'sr' else 10}-step sample images/sec",
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
