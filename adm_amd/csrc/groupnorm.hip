@@ -514,9 +514,12 @@ inline int gn_threads(int C) { return (C / 4) * gn_rows_par(C); }
 
 extern "C" int adm_gn_splits(int HW, int C) {
   (void)C;
+  // one workgroup per (image, split): 64-row splits up to 1024 pixels (the CIFAR maps: <= 16 splits, unchanged), then 256-row
+  // splits so that the 128x128 latents / 512x512 autoencoder maps of the SR recipe still launch thousands of workgroups
   int s = HW / 64;
   if (s < 1) s = 1;
-  if (s > 16) s = 16;
+  if (s > 16) s = HW / 256;
+  if (s > 1024) s = 1024;
   return s;
 }
 
