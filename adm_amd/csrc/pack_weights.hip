@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 // (out-channel) x 32 (in-channel) tile of one layer: the tile's taps-interleaved source runs (32*taps contiguous floats per
 // out-channel) go through LDS once and leave as 128-byte row segments of every operand layout, so reads and writes are
 // coalesced (the previous element-per-thread gather ran at 0.7 TB/s and cost 3.8 ms per optimiser step).
-constexpr int PT_COLS = 12;
+constexpr int PT_COLS = 14;
 __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict__ table, int n_entries) {
   __shared__ float tile[32][32 * 9 + 1];
   // layer of this tile: last row whose tile_begin <= blockIdx.x
@@ -161,6 +161,38 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
       wf[o + plane] = (g0 + g1 + g2) * 0.5f;
       wf[o + 2 * plane] = (g0 - g1 + g2) * 0.5f;
       wf[o + 3 * plane] = g2;
+    }
+  }
+  // 2-D Winograd F(2x2, 3x3) operands (conv_wino2d.hip): U = G g G^T, plane ey * 4 + ex
+  float* __restrict__ wf2 = reinterpret_cast<float*>(t[12]);
+  float* __restrict__ wb2 = reinterpret_cast<float*>(t[13]);
+  if (wf2 || wb2) {
+    const long plane2 = (long)Co_pad * Ci_pad;
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+      // forward operand: ci fastest; data-gradient operand: co fastest -> two index maps over the same 32 x 32 tile
+      for (int which = 0; which < 2; ++which) {
+        float* __restrict__ dst = which ? wb2 : wf2;
+        if (!dst) continue;
+        const int fast = e & 31, slow = e >> 5;
+        const int co_l = which ? fast : slow, ci_l = which ? slow : fast;
+        const float* g = &tile[co_l][ci_l * 9];
+        float tr[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const int ra = which ? 2 - a : a;            // flipped filter for the data gradient
+          const float g0 = which ? g[ra * 3 + 2] : g[ra * 3], g1 = g[ra * 3 + 1], g2 = which ? g[ra * 3] : g[ra * 3 + 2];
+          tr[a][0] = g0; tr[a][1] = (g0 + g1 + g2) * 0.5f; tr[a][2] = (g0 - g1 + g2) * 0.5f; tr[a][3] = g2;
+        }
+        const long o = which ? (long)(ci0 + ci_l) * Co_pad + co0 + co_l : (long)(co0 + co_l) * Ci_pad + ci0 + ci_l;
+#pragma unroll
+        for (int ex = 0; ex < 4; ++ex) {
+          const float c0 = tr[0][ex], c1 = tr[1][ex], c2 = tr[2][ex];
+          dst[(long)(0 * 4 + ex) * plane2 + o] = c0;
+          dst[(long)(1 * 4 + ex) * plane2 + o] = (c0 + c1 + c2) * 0.5f;
+          dst[(long)(2 * 4 + ex) * plane2 + o] = (c0 - c1 + c2) * 0.5f;
+          dst[(long)(3 * 4 + ex) * plane2 + o] = c2;
+        }
+      }
     }
   }
   if (wb) {                                        // wb[xi][ci][ky'][co]: co fastest; g'(ky', kx') = w(2-ky', 2-kx')

@@ -26,6 +26,8 @@ _SIGS = {
     "adm_conv_fwd_wino": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_wino_up": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "adm_pack_weight_wino": [P, P, P, I, I, I, I, P],
+    "adm_pack_weight_wino2d": [P, P, P, I, I, I, I, P],
+    "adm_conv_fwd_wino2d": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],

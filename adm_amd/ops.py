@@ -61,7 +61,7 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 # packed-weight cache
 # ------------------------------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "src")
+    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "src")
 
 
 # Contraction precision of the conv / Linear kernels: "f32" (default: exact fp32 MFMA) or "bf16" (BASELINE
@@ -73,6 +73,9 @@ COMPUTE = "f32"
 # level).  ADM_WINOGRAD=0 keeps every conv on the direct implicit GEMM.
 WINOGRAD = os.environ.get("ADM_WINOGRAD", "1") != "0"
 WINO_MIN_M = 8192
+# ... and those with an even height too (not the fused nearest-x2 ones) through the 2-D F(2x2, 3x3) kernel (adm_conv_fwd_wino2d:
+# 2.25x fewer MFMA flops than the direct kernel).  ADM_WINOGRAD2D=0 keeps them on the 1-D kernel.
+WINOGRAD2D = os.environ.get("ADM_WINOGRAD2D", "1") != "0"
 
 # ADM_DETERMINISTIC=1: bitwise reproducible backward.  The weight / bias gradient kernels normally combine their pixel-range
 # splits with fp32 atomics (order-dependent rounding); with this switch every split stores its partial tile to a workspace
@@ -114,6 +117,20 @@ def _wino_operands(weight: torch.Tensor, ent: "_Packed"):
     return ent.wf, ent.wb
 
 
+def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
+    """2-D Winograd operands (G g G^T, 16 planes) of a packed 3x3 entry, built on first use; refreshed by repack_all()."""
+    if ent.w2f is None:
+        global _pack_table
+        co, ci = weight.shape[0], weight.shape[1]
+        cop, cip = ceil32(co), ceil32(ci)
+        w = _chk(weight.detach(), "weight")
+        ent.w2f = _new((16, cop, cip), w)
+        ent.w2b = _new((16, cip, cop), w)
+        call("adm_pack_weight_wino2d", ptr(w), ptr(ent.w2f), ptr(ent.w2b), co, ci, cop, cip)
+        _pack_table = None
+    return ent.w2f, ent.w2b
+
+
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
 
 
@@ -134,6 +151,7 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     ent.key = key
     ent.fwd16 = ent.bwd16 = None
     ent.wf = ent.wb = None
+    ent.w2f = ent.w2b = None
     ent.src = (co, ci, ks, qkv)
     ent.fwd = _new((cop, ks * ks * cip), w)
     ent.bwd = _new((cip, ks * ks * cop), w)
@@ -185,7 +203,8 @@ def repack_all():
             co, ci = w.shape[0], w.shape[1]
             cop, cip = ceil32(co), ceil32(ci)
             rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv), tiles,
-                         0 if ent.wf is None else ent.wf.data_ptr(), 0 if ent.wb is None else ent.wb.data_ptr()])
+                         0 if ent.wf is None else ent.wf.data_ptr(), 0 if ent.wb is None else ent.wb.data_ptr(),
+                         0 if ent.w2f is None else ent.w2f.data_ptr(), 0 if ent.w2b is None else ent.w2b.data_ptr()])
             tiles += (cop // 32) * (cip // 32)         # column 9 = exclusive prefix sum of 32x32 tiles
             ents.append((wref, bref, ks, qkv, ent))
         if not rows:
@@ -272,9 +291,16 @@ def _use_wino(B, Ho, Wo, ks, up, tile) -> bool:
     return WINOGRAD and ks == 3 and tile < 0 and (Wo & 1) == 0 and B * Ho * Wo >= WINO_MIN_M
 
 
-def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None):
-    """fp32 conv: Winograd F(2,3) kernel when `wq` (its operand) is given, else the direct implicit GEMM; small-M problems
-    get the deterministic split-K path (workspace + fixed-order reduce)."""
+def _use_wino2d(B, Ho, Wo, ks, up, tile) -> bool:
+    return WINOGRAD2D and not up and (Ho & 1) == 0 and _use_wino(B, Ho, Wo, ks, up, tile)
+
+
+def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None, wq2=None):
+    """fp32 conv: 2-D Winograd F(2x2,3x3) kernel when `wq2` is given, 1-D F(2,3) when `wq`, else the direct implicit GEMM;
+    small-M problems get the deterministic split-K path (workspace + fixed-order reduce)."""
+    if wq2 is not None:
+        call("adm_conv_fwd_wino2d", ptr(x), ptr(wq2), ptr(bias), ptr(res), ptr(y), B, Ho, Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
+        return
     if wq is not None:
         call("adm_conv_fwd_wino_up" if up else "adm_conv_fwd_wino", ptr(x), ptr(wq), ptr(bias), ptr(res), ptr(y), B, Ho, Wo,
              cin_p, cin_p, n_p, n_p, n_p, n_p)
@@ -309,14 +335,17 @@ class _Conv(torch.autograd.Function):
                 raise RuntimeError(f"residual shape {tuple(res.shape)} != output {tuple(y.shape)}")
         bf16 = COMPUTE == "bf16"
         use_bf16 = bf16 and cip % 64 == 0
-        wq = _wino_operands(weight, pk)[0] if (not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv) else None
-        with _Prof("wino" if wq is not None else "igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks,
-                   f"fwd{'-wino' if wq is not None else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
+        wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv
+        wq2 = _wino2_operands(weight, pk)[0] if (wino and _use_wino2d(B, Ho, Wo, ks, up, tile)) else None
+        wq = _wino_operands(weight, pk)[0] if (wino and wq2 is None) else None
+        kind = "wino2" if wq2 is not None else "wino" if wq is not None else "igemm"
+        with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
+                   f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
             if use_bf16:
                 call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
                      Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
-                _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq)
+                _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq, wq2)
         ctx.save_for_backward(x, weight, bias)
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
         return y
@@ -424,14 +453,17 @@ class _Conv(torch.autograd.Function):
             pk = packed(weight, bias, ks, qkv)
             dxf = _new((B, Ho, Wo, cip), dy)
             use_bf16 = bf16 and cop % 64 == 0
-            wq = _wino_operands(weight, pk)[1] if (not use_bf16 and _use_wino(B, Ho, Wo, ks, False, -1) and not qkv) else None
-            with _Prof("wino" if wq is not None else "igemm", 2.0 * B * Ho * Wo * co * ci * ks * ks,
-                       f"dgrad{'-wino' if wq is not None else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
+            wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, False, -1) and not qkv
+            wq2 = _wino2_operands(weight, pk)[1] if (wino and _use_wino2d(B, Ho, Wo, ks, False, -1)) else None
+            wq = _wino_operands(weight, pk)[1] if (wino and wq2 is None) else None
+            kind = "wino2" if wq2 is not None else "wino" if wq is not None else "igemm"
+            with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
+                       f"dgrad{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
                 if use_bf16:
                     call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
                          cop, cop, cip, cip, cip, cip, ks, 0, -1)
                 else:
-                    _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1, wq)
+                    _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1, wq, wq2)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
                 call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)

@@ -292,8 +292,7 @@ def main():
         # Winograd kernels execute 2/3 of the direct convolution's 2*M*N*9*Cin -- so frac = achieved / peak is a true roofline
         # fraction (<= 1) and is comparable with the PMC MFMA-busy fraction; the ALGORITHMIC (direct-convolution) rate, which
         # is what images/s follow, is carried beside it as `algorithmic` / `algorithmic_over_peak` (may exceed 1).
-        wino = by.get("wino")
-        dom_kind = "wino" if wino and wino[1] > by.get("igemm", [0, 0, 0])[1] else "igemm"
+        dom_kind = max((k for k in ("wino2", "wino", "igemm") if k in by), key=lambda k: by[k][1])
         # HBM-side traffic per launch comes from rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
         # WRITE_SIZE runs, FETCH doubled per MI355X_MICROARCH.md): counters cannot be read from inside the process.
         traffic_src, pmc_all = None, {}
@@ -306,8 +305,9 @@ def main():
         if args.dtype != "f32" or args.config != "cifar":
             pmc_all, traffic_src = {}, None    # the committed PMC passes are of the fp32 CIFAR run
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        EXEC = {"wino": 2.0 / 3.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
-        NAMES = {"wino": "igemm_wino_kernel (3x3 conv forward + data-gradient, Winograd F(2,3), fp32 MFMA)",
+        EXEC = {"wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
+        NAMES = {"wino2": "igemm_wino2d_kernel (3x3 conv forward + data-gradient, 2-D Winograd F(2x2,3x3), fp32 MFMA)",
+                 "wino": "igemm_wino_kernel (3x3 conv forward + data-gradient, Winograd F(2,3): fused-upsample / odd-height layers)",
                  "igemm": ("igemm_f32_kernel" if args.dtype == "f32" else "igemm_bf16_kernel") +
                           " (1x1 / Linear / small-map / fused-upsample convs: forward + data-gradient)",
                  "wgrad_wino": "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3,2))",
@@ -335,9 +335,9 @@ def main():
         roof.update({"traffic_unit": "bytes/launch (L2-miss side: HBM + Infinity Cache), rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE",
                      "traffic_source": traffic_src,
                      "note": "achieved = EXECUTED MFMA flops / kernel time (HIP events around every launch of one profiled step); "
-                             "frac = achieved / peak.  Winograd F(2,3) executes 2/3 of the direct convolution's flops: "
+                             "frac = achieved / peak.  Winograd executes 4/9 (2-D F(2x2,3x3)) or 2/3 (1-D F(2,3)) of the direct convolution's flops: "
                              "`algorithmic` is the direct-convolution rate (SURVEY 8d's 213.9 GFLOP/image figures)."})
-        for kind, key in (("igemm", "igemm_direct"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
+        for kind, key in (("wino", "wino_1d"), ("igemm", "igemm_direct"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
             if kind in by and kind != dom_kind:
                 roof[key] = mfma_entry(kind)
         # whole step against the MFMA roof: every GEMM-shaped launch of the profiled step

@@ -93,6 +93,13 @@ int adm_conv_wgrad_wino(const float* x, const float* dy, float* dwp, float* dbia
 int adm_conv_wgrad_wino_up(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx,
                            int Cout, int lddy, int splits, hipStream_t stream);
 
+/* 2-D Winograd F(2x2, 3x3) forward / data gradient (conv_wino2d.hip): 2.25x fewer MFMA flops than adm_conv_fwd, 1.5x fewer
+ * than adm_conv_fwd_wino; H and W even, Cin % 16 == 0.  wq = adm_pack_weight_wino2d operand: wf[16][Co_pad][Ci_pad] (forward)
+ * or wb[16][Ci_pad][Co_pad] (data gradient, taps flipped), plane index ey * 4 + ex of U = G g G^T. */
+int adm_pack_weight_wino2d(const float* w, float* wf, float* wb, int Co, int Ci, int Co_pad, int Ci_pad, hipStream_t stream);
+int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H, int W,
+                        int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
+
 /* Deterministic weight gradients (bitwise reproducible backward; SURVEY.md section 5.2 "run twice, bit-compare").  The
  * kernels above combine their pixel-range splits with fp32 atomics.  Here split z writes its partial tile with plain stores
  * to ws[z][Cout][ks*ks][Cin] (and its bias partial to bws[z][Cout], bws may be NULL) and adm_unpack_wgrad_splits sums the
@@ -123,7 +130,7 @@ int adm_pack_weight(const float* w, float* wp_fwd, float* wp_bwd, int Co, int Ci
                     int qkv, hipStream_t stream);
 /* adm_pack_weight (+ adm_pack_weight_wino) for every layer of a model in ONE launch (used after each optimiser step).
  * table = device array of n_entries rows of 12 int64: {src, dst_fwd, dst_bwd, Co, Ci, ks*ks, Co_pad, Ci_pad, qkv, tile_begin,
- * dst_wino_fwd, dst_wino_bwd}; tile_begin = the exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) in row order; total_tiles =
+ * dst_wino_fwd, dst_wino_bwd, dst_wino2d_fwd, dst_wino2d_bwd}; tile_begin = the exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) in row order; total_tiles =
  * the sum; the Winograd destinations may be 0.  dst_fwd / dst_bwd are required. */
 int adm_pack_weight_table(const long* table, int n_entries, long total_tiles, hipStream_t stream);
 /* inverse of the fwd packing for gradients: dw OIHW = (accumulate ? dw : 0) + dwp */

@@ -89,6 +89,7 @@ def test_conv_winograd_forward_backward(ops, monkeypatch, B, cin, cout, H, W, up
     kernel.  Also checked against the direct kernel, which must agree to rounding."""
     monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD2D", False)       # the 1-D kernel under test (even-height shapes would take the 2-D one)
     x = fill.hash_tensor((B, cin, H, W), f"wx{cin}{cout}", 1.0)
     w = fill.hash_tensor((cout, cin, 3, 3), f"ww{cin}{cout}", 1.0 / math.sqrt(cin * 9))
     b = fill.hash_tensor((cout,), f"wb{cin}{cout}", 0.5)
@@ -116,6 +117,46 @@ def test_conv_winograd_forward_backward(ops, monkeypatch, B, cin, cout, H, W, up
     with torch.no_grad():
         yd = ops.conv2d(xd.detach(), dev(w), dev(b), rd.detach(), up=up)
     assert float((y.detach() - yd).abs().max()) <= 1e-5 * float(yd.abs().max())
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(3, 32, 32, 8, 8), (2, 64, 96, 6, 10), (1, 3, 64, 16, 16), (2, 96, 3, 4, 32), (4, 192, 192, 16, 16),
+                                            (1, 32, 32, 2, 2), (2, 384, 384, 8, 8), (8, 64, 96, 32, 32), (2, 768, 384, 16, 16),
+                                            (130, 32, 64, 2, 4)])
+def test_conv_winograd_2d_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
+    """The 2-D F(2x2,3x3) kernel (conv_wino2d.hip; 2.25x fewer MFMA flops): forward and data gradient against F.conv2d on the CPU
+    and against the direct kernel; channel padding on both sides, 2x2 images, ragged tile counts, bias + residual."""
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD2D", True)
+    x = fill.hash_tensor((B, cin, H, W), f"w2x{cin}{cout}{H}", 1.0)
+    w = fill.hash_tensor((cout, cin, 3, 3), f"w2w{cin}{cout}", 1.0 / math.sqrt(cin * 9))
+    b = fill.hash_tensor((cout,), f"w2b{cin}{cout}", 0.5)
+    r = fill.hash_tensor((B, cout, H, W), f"w2r{cin}{cout}{H}", 1.0)
+    gy = fill.hash_tensor((B, cout, H, W), f"w2g{cin}{cout}{H}", 1.0)
+    xr, wr, br, rr = [t.clone().requires_grad_(True) for t in (x, w, b, r)]
+    y_ref = F.conv2d(xr, wr, br, padding=1) + rr
+    (y_ref * gy).sum().backward()
+    cip, cop = ops.ceil32(cin), ops.ceil32(cout)
+    xd = nhwc(pad_c(x, cip)).requires_grad_(True)
+    wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    rd = nhwc(pad_c(r, cop)).requires_grad_(True)
+    monkeypatch.setattr(ops, "PROFILE", [])
+    y = ops.conv2d(xd, wd, bd, rd)
+    assert wd._adm_packed.w2f is not None and wd._adm_packed.wf is None, "the 2-D Winograd path was not taken"
+    close(nchw(y)[:, :cout], y_ref)
+    if cop > cout:
+        assert float(y.detach()[..., cout:].abs().max()) == 0.0
+    (y * nhwc(pad_c(gy, cop))).sum().backward()
+    assert [rec[0] for rec in ops.PROFILE].count("wino2") == 2          # forward + data gradient
+    close(nchw(xd.grad)[:, :cin], xr.grad)
+    close(wd.grad, wr.grad)
+    close(bd.grad, br.grad)
+    close(nchw(rd.grad)[:, :cout], rr.grad)
+    monkeypatch.setattr(ops, "WINOGRAD", False)
+    with torch.no_grad():
+        yd = ops.conv2d(xd.detach(), dev(w), dev(b), rd.detach())
+        assert float((y.detach() - yd).abs().max()) <= 2e-5 * float(yd.abs().max())
+        assert torch.equal(y.detach(), ops.conv2d.__wrapped__(xd.detach(), dev(w), dev(b), rd.detach())) if hasattr(ops.conv2d, "__wrapped__") else True
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W,up,force", [
