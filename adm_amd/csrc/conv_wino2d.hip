@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
   const int KT = 4 * chunks;                      // four passes (ey) over K = Cin
   int ld_ey = 0, ld_cc = 0;
   f32x4 dA[4], dB[4];
-  float sA = 1.f, sB = 1.f;                       // signs of the two rows of the pass being LOADED (consumed by store_stage)
+  int st_ey = 0;                                  // pass of the stage being LOADED (consumed by store_stage: selects the signs)
   auto issue_stage = [&](int buf) {               // global -> registers (A), global -> LDS (B) for the NEXT stage
     if (ld_cc == 0) {
       // pass ey combines input rows (iA, iB) of the 4-row patch: 0: +r0 -r2   1: +r1 +r2   2: -r1 +r2   3: +r1 -r3
@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
       dA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[0][j], soff, 0));
       dB[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[1][j], soff, 0));
     }
-    sA = (ld_ey == 2) ? -1.f : 1.f;
-    sB = (ld_ey == 0 || ld_ey == 3) ? -1.f : 1.f;
+    st_ey = ld_ey;
     const int kb = (ld_ey * 4 * p.plane) * 4 + soff;       // plane block of this ey; the wave's ex plane is in b_voff
     float* lb = Bs + (buf * 4 + wid) * W2N * W2K;
 #pragma unroll
@@ -125,8 +124,16 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
   };
   auto store_stage = [&](int buf) {               // y combination, then B^T along x, into the four ex planes
     f32x4 e[4];
+    if (st_ey == 1) {                             // wave-uniform: one add / sub per element instead of a multiply-add pair
 #pragma unroll
-    for (int j = 0; j < 4; ++j) e[j] = dA[j] * sA + dB[j] * sB;
+      for (int j = 0; j < 4; ++j) e[j] = dA[j] + dB[j];
+    } else if (st_ey == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = dB[j] - dA[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = dA[j] - dB[j];
+    }
     float* la = As + buf * 4 * W2P * W2K + pl * W2K + a_slot;
     *reinterpret_cast<f32x4*>(la + 0 * W2P * W2K) = e[0] - e[2];
     *reinterpret_cast<f32x4*>(la + 1 * W2P * W2K) = e[1] + e[2];
@@ -136,10 +143,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
 
   f32x16 acc[4];
   f32x16 Y[2][2];                                 // [output row][output column of the pair]
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -168,11 +171,22 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
         a[xi] = *reinterpret_cast<const f32x4*>(Ab + xi * W2P * W2K + foff[g]);
         b[xi] = *reinterpret_cast<const f32x4*>(Bb + xi * W2N * W2K + foff[g]);
       }
+      if (g == 0 && cc == 0) {                    // first products of a pass: C = 0 (inline constant), no accumulator clearing
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+        for (int xi = 0; xi < 4; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[xi][0], b[xi][0], zero, 0, 0, 0);
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
-          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[xi][k], b[xi][k], acc[xi], 0, 0, 0);
+        for (int k = 1; k < 4; ++k)
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi)
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[xi][k], b[xi][k], acc[xi], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi)
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[xi][k], b[xi][k], acc[xi], 0, 0, 0);
+      }
     }
     if (s + 1 < KT) store_stage(buf ^ 1);         // the other buffer was last read in stage s-1: every wave passed its barrier
     if (++cc == chunks) {
@@ -185,7 +199,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
         if (ey <= 2) { Y[0][0][r] += z0; Y[0][1][r] += z1; }
         if (ey == 1) { Y[1][0][r] += z0; Y[1][1][r] += z1; }
         if (ey >= 2) { Y[1][0][r] -= z0; Y[1][1][r] -= z1; }
-        acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; acc[3][r] = 0.f;
       }
       ++ey;
     }
