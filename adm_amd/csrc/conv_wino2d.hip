@@ -27,6 +27,10 @@
 #include "common.h"
 #include "../../include/adm_hip.h"
 
+#ifndef W2_ABL
+#define W2_ABL 0      // diagnostic builds (tools/bench_wino2d.cpp): 1 no A global loads, 2 no A transform / LDS stores, 4 no B DMA, 8 no LDS fragment reads
+#endif
+
 namespace {
 
 struct Wino2P {
@@ -111,18 +115,22 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
     const int soff = ld_cc << 6;                  // 16 floats = 64 bytes per chunk
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (W2_ABL & 1) { dA[j] = f32x4{1.f, 2.f, 3.f, (float)soff}; dB[j] = f32x4{0.5f, 0.25f, (float)j, 1.f}; continue; }
       dA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[0][j], soff, 0));
       dB[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[1][j], soff, 0));
     }
     st_ey = ld_ey;
     const int kb = (ld_ey * 4 * p.plane) * 4 + soff;       // plane block of this ey; the wave's ex plane is in b_voff
     float* lb = Bs + (buf * 4 + wid) * W2N * W2K;
+    if (!(W2_ABL & 4)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (wino2_lds_void*)(lb + i * 16 * W2K), 16, (int)b_voff[i], kb, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (wino2_lds_void*)(lb + i * 16 * W2K), 16, (int)b_voff[i], kb, 0, 0);
+    }
     if (++ld_cc == chunks) { ld_cc = 0; ++ld_ey; }
   };
   auto store_stage = [&](int buf) {               // y combination, then B^T along x, into the four ex planes
+    if (W2_ABL & 2) return;
     f32x4 e[4];
     if (st_ey == 1) {                             // wave-uniform: one add / sub per element instead of a multiply-add pair
 #pragma unroll
@@ -154,6 +162,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
 #pragma unroll
   for (int g = 0; g < 2; ++g) foff[g] = lr * W2K + (((2 * g + lh) ^ ((lr >> 2) & 3)) << 2);
 
+  // Two workgroups share a CU (one wave of each per SIMD) and run the same program; the workgroups of the second resident slot
+  // start half a stage later so that the pair does not reach its barriers and LDS bursts in lockstep (MI355X_MICROARCH.md,
+  // 'Two waves per SIMD', item 9).  Measured: +1-2 % only -- see DESIGN.md for what does limit this kernel.
+  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(16);
   issue_stage(0);
   store_stage(0);
   __syncthreads();
@@ -168,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
       f32x4 a[4], b[4];
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) {
+        if (W2_ABL & 8) { a[xi] = f32x4{1.f, (float)s, (float)lane, 2.f}; b[xi] = f32x4{(float)xi, 1.f, 0.5f, (float)g}; continue; }
         a[xi] = *reinterpret_cast<const f32x4*>(Ab + xi * W2P * W2K + foff[g]);
         b[xi] = *reinterpret_cast<const f32x4*>(Bb + xi * W2N * W2K + foff[g]);
       }
