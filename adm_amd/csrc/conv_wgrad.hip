@@ -320,12 +320,12 @@ extern "C" int adm_conv_wgrad_bias(const float* x, const float* dy, float* dwp, 
   return wgrad_impl(x, dy, dwp, dbias, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, 0, 0, false, stream);
 }
 
-int adm_wgrad_wino_plan(int B, int H, int W, int Cin, int Cout);      // conv_wgrad_wino.hip
+int adm_wgrad_wino_plan(int B, int H, int W, int Cin, int Cout, int mode);      // conv_wgrad_wino.hip; mode 0 / 1 (up) / 2 (2-D)
 int adm_wgrad_wino_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
-                      int lddy, int splits, int up, hipStream_t stream);
+                      int lddy, int splits, int mode, hipStream_t stream);
 
 extern "C" int adm_conv_wgrad_plan(int B, int H, int W, int Cin, int Cout, int ks, int up, int wino) {
-  if (wino) return adm_wgrad_wino_plan(B, H, W, Cin, Cout);
+  if (wino) return adm_wgrad_wino_plan(B, H, W, Cin, Cout, wino == 2 ? 2 : (up ? 1 : 0));
   return wgrad_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, ks, up, 0, 0, 0, true, nullptr);
 }
 
@@ -334,7 +334,7 @@ extern "C" int adm_conv_wgrad_ws(const float* x, const float* dy, float* ws, flo
   if (splits < 1 || !ws) return ADM_EINVAL;
   if (wino) {
     if (ks != 3) return ADM_EINVAL;
-    return adm_wgrad_wino_ws(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, up, stream);
+    return adm_wgrad_wino_ws(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, wino == 2 ? 2 : (up ? 1 : 0), stream);
   }
   return wgrad_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, (long)Cout * ks * ks * Cin, Cout, false,
                     stream);

@@ -16,6 +16,16 @@
 // write DIFFERENT channel residues in each store round so that the transposing ds_write_b32 stays conflict-free).
 // The bias gradient rides along: sum(e0 + e1) is the xi = 1 component of A e.
 // Power-of-two H and W only (every DDM shape); anything else stays on conv_wgrad.hip.
+//
+// MODE 2 = the same nested along y: the transposed 2-D form F(3x3, 2x2).  Per 2x2 tile of dY and the 4x4 patch of X around it,
+//     a = A e A^T (4x4 from 2x2)     b = B^T d B (4x4)     m[ey][ex] = sum_tiles a[ey][ex] * b[ey][ex]     dW = G^T m G
+// i.e. 16 products per (tile, co, ci) instead of the 1-D form's 24 (the direct kernel: 36): 1.5x less MFMA work again.  The y
+// index takes the place of the filter row in the grid (gridDim.y = 4 instead of 3): workgroup `ey` reduces over TILES the
+// y-combined rows  a_y = (e_r0, e_r0 + e_r1, e_r0 - e_r1, -e_r1)[ey]  of dY and  (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey]  of X
+// through the unchanged x pipeline (A e / B^T d, four ex GEMMs, G^T along x in the epilogue) and writes wx[co][ey][kx][ci];
+// the y half of G^T, dW[ky] = sum_ey Gt[ky][ey] wx[ey], is applied by the unpack launch that follows anyway
+// (adm_unpack_wgrad_wino2d).  Same accumulators, LDS and occupancy as the 1-D form; 11 instead of 6 pixel loads per stage for
+// 2/3 of the stages.
 #include <algorithm>
 #include "common.h"
 #include "../../include/adm_hip.h"
@@ -24,14 +34,16 @@ namespace {
 
 struct WwP {
   const float* x; const float* dy; float* dwp; float* dbias;
-  int Pp, H, W, lw, lh, Cin, ldx, Cout, lddy, tilesN, chunk, atomic, xbytes, dybytes;   // Pp = pixel pairs, chunk in pairs
+  int Pp, H, W, lw, lh, Cin, ldx, Cout, lddy, tilesN, chunk, atomic, xbytes, dybytes;   // Pp = pixel pairs (MODE 2: 2x2 tiles), chunk likewise
+  int taps;                                                                              // rows per cout of dwp: 9 (1-D) or 12 = 4 ey x 3 kx (MODE 2)
   long split_stride, bias_stride;      // > 0: deterministic mode, partials of split z at dwp + z * split_stride (plain stores)
 };
 
 constexpr int WT = 64, WKK = 16;       // 64 x 64 channel tile, 16 pairs per stage
 
-template <bool UP>
+template <int MODE>      // 0: 1-D F(3,2); 1: the same with the conv's fused nearest x2 (x is half resolution); 2: 2-D F(3x3, 2x2)
 __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
+  constexpr bool UP = MODE == 1, TWOD = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                               // [4][WT][WKK]   a_xi, rows = cout  (single-buffered: see the loop)
   float* Bs = smem + 4 * WT * WKK;                // [4][WT][WKK]   b_xi, rows = cin
@@ -62,10 +74,50 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
   const int Wh = p.W >> 1;
 
   f32x4 e[2], d[4];
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
   auto load_stage = [&](int s) {
     const int pb = pbeg + s * WKK;
-    const int pr = pb + lk;                                         // this thread's pair
+    const int pr = pb + lk;                                         // this thread's pair (MODE 2: its 2x2 tile)
     const bool pv = pr < pend;
+    if (TWOD) {
+      // tile (b, ty, xp): top-left output pixel (b, 2 ty, 2 xp) = ((pr >> lwh) << (lw + 1)) + 2 xp    (H, W powers of two)
+      const int ey = ky;                                            // blockIdx.y = y index of the transform
+      const int lwh = p.lw - 1;
+      const int xp = pr & (Wh - 1), ty = (pr >> lwh) & ((p.H >> 1) - 1);
+      const unsigned pix = ((unsigned)(pr >> lwh) << (p.lw + 1)) + 2u * (unsigned)xp;
+      // dY rows 2ty (r0) and 2ty + 1 (r1): a_y = (r0, r0 + r1, r0 - r1, -r1)[ey]
+      const unsigned ya = (pv && a_col != OOB) ? pix * (unsigned)p.lddy * 4u + a_col : OOB;
+      const unsigned ystep = (unsigned)p.lddy * 4u, yrow = (unsigned)p.W * ystep;
+      f32x4 t0[2], t1[2];
+      if (ey != 3) {
+        t0[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)ya, 0, 0));
+        t0[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(ya != OOB ? ya + ystep : OOB), 0, 0));
+      }
+      if (ey != 0) {
+        t1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(ya != OOB ? ya + yrow : OOB), 0, 0));
+        t1[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(ya != OOB ? ya + yrow + ystep : OOB), 0, 0));
+      }
+      // X rows 2ty - 1 + i: (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey], columns 2xp - 1 .. 2xp + 2
+      const int iA = (ey == 0) ? 0 : 1, iB = (ey == 3) ? 3 : 2;
+      const bool vA = pv && b_col != OOB && (iA != 0 || ty > 0), vB = pv && b_col != OOB && (iB != 3 || ty < (p.H >> 1) - 1);
+      const unsigned xstep = (unsigned)p.ldx * 4u;
+      const unsigned xa = pix * xstep + b_col + (unsigned)((iA - 1) * p.W - 1) * xstep;      // row iA, column 2xp - 1 (may wrap: masked)
+      const unsigned xb = pix * xstep + b_col + (unsigned)((iB - 1) * p.W - 1) * xstep;
+      f32x4 u0[4], u1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool cv = (j != 0 || xp > 0) && (j != 3 || xp < Wh - 1);
+        u0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x0, (int)((vA && cv) ? xa + j * xstep : OOB), 0, 0));
+        u1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x0, (int)((vB && cv) ? xb + j * xstep : OOB), 0, 0));
+      }
+      if (ey == 0) { e[0] = t0[0]; e[1] = t0[1]; }
+      else if (ey == 1) { e[0] = t0[0] + t1[0]; e[1] = t0[1] + t1[1]; }
+      else if (ey == 2) { e[0] = t0[0] - t1[0]; e[1] = t0[1] - t1[1]; }
+      else { e[0] = -t1[0]; e[1] = -t1[1]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = (ey == 1) ? u0[j] + u1[j] : (ey == 2) ? u1[j] - u0[j] : u0[j] - u1[j];
+      return;
+    }
     const int xp = pr & (Wh - 1), y = (pr >> (p.lw - 1)) & (p.H - 1);
     const bool rv = pv && (unsigned)(y + ky - 1) < (unsigned)p.H;
     const int a_soff = 2 * pb * p.lddy * 4, b_soff = 2 * pb * p.ldx * 4;
@@ -93,7 +145,9 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
     d[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(rv ? bv + 2 * step : OOB), b_soff, 0));
     d[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)((rv && xp < Wh - 1) ? bv + 3 * step : OOB), b_soff, 0));
   };
-  const bool do_bias = p.dbias != nullptr && tn == 0 && ky == 0;
+  // the bias gradient = sum of every dY pixel = the ex = 1 component (e0 + e1 along x) of the filter row 0 workgroups; in MODE 2
+  // of the ey = 1 workgroups, whose y combination is r0 + r1
+  const bool do_bias = p.dbias != nullptr && tn == 0 && ky == (TWOD ? 1 : 0);
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   // transposing store: element (channel c = quad*4 + jj, pair lk) of plane xi -> row c, swizzled column
   //   float offset = c*16 + (((lk >> 2) ^ ((c >> 2) & 3)) << 2) + (lk & 3),  (c >> 2) & 3 = quad & 3
@@ -179,7 +233,7 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
     if (co >= p.Cout) continue;
     const float h = 0.5f * (acc[1][r] + acc[2][r]);
     const float w0 = acc[0][r] + h, w1 = 0.5f * (acc[1][r] - acc[2][r]), w2 = h + acc[3][r];
-    float* dst = p.dwp + (long)blockIdx.z * p.split_stride + ((long)co * 9 + ky * 3) * p.Cin + ci;
+    float* dst = p.dwp + (long)blockIdx.z * p.split_stride + ((long)co * p.taps + ky * 3) * p.Cin + ci;
     if (p.atomic) {
       atomicAdd(dst, w0); atomicAdd(dst + p.Cin, w1); atomicAdd(dst + 2 * p.Cin, w2);
     } else {
@@ -192,7 +246,9 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
 
 namespace {
 int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                    int lddy, int splits, int up, bool det, bool plan_only, hipStream_t stream) {
+                    int lddy, int splits, int mode, bool det, bool plan_only, hipStream_t stream) {
+  const int up = mode == 1, twod = mode == 2;
+  if (mode < 0 || mode > 2 || (twod && H < 2)) return ADM_EINVAL;
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
   if (B <= 0 || H <= 0 || W < 2) return ADM_EINVAL;
   if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
@@ -206,10 +262,11 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
   const long P = (long)B * H * W;
   const long xb = (up ? P / 4 : P) * ldx * 4, db = P * lddy * 4;
   if (xb >= (1L << 31) - (1L << 22) || db >= (1L << 31) - (1L << 22)) return ADM_EINVAL;   // 32-bit offsets, with room for the tap shift
-  p.Pp = (int)(P / 2); p.H = H; p.W = W; p.lw = lw; p.lh = lh; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
+  p.Pp = (int)(twod ? P / 4 : P / 2); p.taps = twod ? 12 : 9; p.H = H; p.W = W; p.lw = lw; p.lh = lh; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, WT);
-  const long tiles = (long)adm_cdiv(Cout, WT) * p.tilesN * 3;
+  const int gy = twod ? 4 : 3;
+  const long tiles = (long)adm_cdiv(Cout, WT) * p.tilesN * gy;
   if (splits <= 0) {
     // 768 resident slots (3 workgroups per CU).  Pick the split count whose workgroup total fills whole rounds best
     // (tiles * s close below a multiple of 768), with a mild preference for fewer splits (atomics, shorter K loops);
@@ -229,23 +286,26 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
   splits = (p.Pp + chunk - 1) / chunk;
   if (plan_only) return splits;
   p.chunk = chunk;
-  p.split_stride = det ? (long)Cout * 9 * Cin : 0;
+  p.split_stride = det ? (long)Cout * p.taps * Cin : 0;
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
-  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 9 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
+  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * p.taps * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
   constexpr int smem = 4 * (WT + WT) * WKK * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
-  dim3 grid(adm_cdiv(Cout, WT) * p.tilesN, 3, splits);
-  if (up) hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(256), smem, stream, p);
-  else hipLaunchKernelGGL(wgrad_wino_kernel<false>, grid, dim3(256), smem, stream, p);
+  dim3 grid(adm_cdiv(Cout, WT) * p.tilesN, gy, splits);
+  if (twod) hipLaunchKernelGGL(wgrad_wino_kernel<2>, grid, dim3(256), smem, stream, p);
+  else if (up) hipLaunchKernelGGL(wgrad_wino_kernel<1>, grid, dim3(256), smem, stream, p);
+  else hipLaunchKernelGGL(wgrad_wino_kernel<0>, grid, dim3(256), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -264,10 +324,17 @@ extern "C" int adm_conv_wgrad_wino_up(const float* x, const float* dy, float* dw
 
 // Used by adm_conv_wgrad_plan / adm_conv_wgrad_ws (conv_wgrad.hip): the split count the launcher picks, and the deterministic
 // workspace mode (split z writes its partial tile to ws[z][Cout][9][Cin] and its bias partial to bws[z][Cout]).
-int adm_wgrad_wino_plan(int B, int H, int W, int Cin, int Cout) {
-  return wgrad_wino_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, 0, 0, false, true, nullptr);
+int adm_wgrad_wino_plan(int B, int H, int W, int Cin, int Cout, int mode) {
+  return wgrad_wino_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, 0, mode, false, true, nullptr);
 }
 int adm_wgrad_wino_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
-                      int lddy, int splits, int up, hipStream_t stream) {
-  return wgrad_wino_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, up, true, false, stream);
+                      int lddy, int splits, int mode, hipStream_t stream) {
+  return wgrad_wino_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, mode, true, false, stream);
+}
+
+// 2-D F(3x3, 2x2) weight gradient (MODE 2 above): dwp2[Cout][4 ey][3 kx][Cin] holds the x-folded planes; adm_unpack_wgrad_wino2d
+// applies G^T along y.  H and W powers of two (H >= 2); dbias as adm_conv_wgrad_wino.
+extern "C" int adm_conv_wgrad_wino2d(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin,
+                                     int ldx, int Cout, int lddy, int splits, hipStream_t stream) {
+  return wgrad_wino_impl(x, dy, dwp2, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, 2, false, false, stream);
 }

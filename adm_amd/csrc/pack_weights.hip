@@ -322,3 +322,43 @@ extern "C" int adm_pack_weight_tconv(const float* w, float* out, int Co, int Ci,
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
+
+namespace {
+// dw[co][ci][ky][kx] (+)= sum_z sum_ey Gt[ky][ey] * wx[z][co][ey][kx][ci],  Gt = G^T rows (1, 1/2, 1/2, 0) (0, 1/2, -1/2, 0) (0, 1/2, 1/2, 1)
+__global__ void unpack_wino2d_kernel(const float* __restrict__ wx, float* __restrict__ dw, int Co, int Ci, int Ci_pad, int accumulate,
+                                     int splits, long split_stride) {
+  const long total = (long)Co * Ci * 3;      // one thread per (co, ci, kx): its three ky taps
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int kx = idx % 3;
+    const long t = idx / 3;
+    const int ci = t % Ci, co = t / Ci;
+    float m[4];
+#pragma unroll
+    for (int ey = 0; ey < 4; ++ey) {
+      const long src = (((long)co * 4 + ey) * 3 + kx) * Ci_pad + ci;
+      float v = wx[src];
+      for (int z = 1; z < splits; ++z) v += wx[z * split_stride + src];
+      m[ey] = v;
+    }
+    const float h = 0.5f * (m[1] + m[2]);
+    const float w[3] = {m[0] + h, 0.5f * (m[1] - m[2]), h + m[3]};
+    float* o = dw + ((long)co * Ci + ci) * 9 + kx;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) o[ky * 3] = accumulate ? o[ky * 3] + w[ky] : w[ky];
+  }
+}
+}  // namespace
+
+// adm_unpack_wgrad (+ _splits) for the output of adm_conv_wgrad_wino2d / adm_conv_wgrad_ws(wino = 2): wx[splits][Co_pad][4][3][Ci_pad]
+extern "C" int adm_unpack_wgrad_wino2d(const float* wx, int splits, float* dw, int Co, int Ci, int Co_pad, int Ci_pad, int accumulate,
+                                       const float* bws, float* dbias, hipStream_t stream) {
+  if (!wx || !dw || splits < 1 || Co <= 0 || Ci <= 0 || Co_pad < Co || Ci_pad < Ci) return ADM_EINVAL;
+  if ((bws == nullptr) != (dbias == nullptr)) return ADM_EINVAL;
+  const long total = (long)Co * Ci * 3;
+  hipLaunchKernelGGL(unpack_wino2d_kernel, dim3((unsigned)min((long)4096, (total + 255) / 256)), dim3(256), 0, stream, wx, dw, Co, Ci,
+                     Ci_pad, accumulate, splits, (long)Co_pad * 12 * Ci_pad);
+  if (bws)
+    hipLaunchKernelGGL(bias_splits_kernel, dim3((Co_pad + 255) / 256), dim3(256), 0, stream, bws, dbias, Co_pad, splits, (long)Co_pad);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}

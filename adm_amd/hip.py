@@ -32,6 +32,8 @@ _SIGS = {
     "adm_conv_wgrad_wino": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bias": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_wino2d": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "adm_unpack_wgrad_wino2d": [P, I, P, I, I, I, I, I, P, P, P],
     "adm_conv_wgrad_plan": [I, I, I, I, I, I, I, I],
     "adm_conv_wgrad_ws": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_unpack_wgrad_splits": [P, I, P, I, I, I, I, I, I, I, P, P, P],

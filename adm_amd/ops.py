@@ -388,23 +388,29 @@ class _Conv(torch.autograd.Function):
                         dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
                 wino_w = (not bf16 and _use_wino(B, Ho, Wo, ks, up, -1) and not qkv and pow2(Ho) and pow2(Wo))
+                wino2_w = wino_w and WINOGRAD2D and not up and Ho >= 2          # 2-D F(3x3, 2x2): 12 x-folded planes per cout
+                wmode = 2 if wino2_w else int(wino_w)
+                planes = 12 if wino2_w else ks * ks
                 det = DETERMINISTIC and not bf16
                 splits = 1
                 if det:        # splits store partial tiles to a workspace; the unpack launch sums them in a fixed order
-                    splits = hip.lib().adm_conv_wgrad_plan(B, Ho, Wo, cip, cop, ks, int(up), int(wino_w))
+                    splits = hip.lib().adm_conv_wgrad_plan(B, Ho, Wo, cip, cop, ks, int(up), wmode)
                     if splits < 1:
                         raise RuntimeError(f"adm_conv_wgrad_plan failed with code {splits}")
-                    dwp = _new((splits, cop, ks * ks * cip), dy)
+                    dwp = _new((splits, cop, planes * cip), dy)
                     bws = _new((splits, cop), dy) if dbp is not None else None
                 else:
-                    dwp = _new((cop, ks * ks * cip), dy)
-                with _Prof("wgrad_wino" if wino_w else "wgrad", 2.0 * B * Ho * Wo * co * ci * ks * ks,
-                           f"wgrad{'-wino' if wino_w else ''} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
+                    dwp = _new((cop, planes * cip), dy)
+                kind = "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
+                with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
+                           f"{kind.replace('_', '-')} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16:
                         call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
                     elif det:
                         call("adm_conv_wgrad_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, ks, int(up),
-                             splits, int(wino_w))
+                             splits, wmode)
+                    elif wino2_w:
+                        call("adm_conv_wgrad_wino2d", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, 0)
                     elif wino_w:
                         call("adm_conv_wgrad_wino_up" if up else "adm_conv_wgrad_wino", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B,
                              Ho, Wo, cip, cip, cop, cop, 0)
@@ -416,7 +422,10 @@ class _Conv(torch.autograd.Function):
                 else:
                     dw = torch.empty_like(weight)
                     dst, acc = dw, 0
-                if det:
+                if wino2_w:      # the y half of G^T rides in the unpack: dW[ky] = sum_ey Gt[ky][ey] wx[ey]
+                    call("adm_unpack_wgrad_wino2d", ptr(dwp), splits, ptr(dst), co, ci, cop, cip, acc, ptr(bws) if det else None,
+                         ptr(dbp) if det else None)
+                elif det:
                     call("adm_unpack_wgrad_splits", ptr(dwp), splits, ptr(dst), co, ci, ks, cop, cip, int(qkv), acc, ptr(bws),
                          ptr(dbp))
                 else:

@@ -305,12 +305,13 @@ def main():
         if args.dtype != "f32" or args.config != "cifar":
             pmc_all, traffic_src = {}, None    # the committed PMC passes are of the fp32 CIFAR run
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        EXEC = {"wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
+        EXEC = {"wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino2": 4.0 / 9.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
         NAMES = {"wino2": "igemm_wino2d_kernel (3x3 conv forward + data-gradient, 2-D Winograd F(2x2,3x3), fp32 MFMA)",
                  "wino": "igemm_wino_kernel (3x3 conv forward + data-gradient, Winograd F(2,3): fused-upsample / odd-height layers)",
                  "igemm": ("igemm_f32_kernel" if args.dtype == "f32" else "igemm_bf16_kernel") +
                           " (1x1 / Linear / small-map / fused-upsample convs: forward + data-gradient)",
-                 "wgrad_wino": "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3,2))",
+                 "wgrad_wino2": "wgrad_wino_kernel<2> (3x3 weight gradient, 2-D Winograd F(3x3,2x2))",
+                 "wgrad_wino": "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3,2): fused-upsample layers)",
                  "wgrad": "wgrad_f32_kernel (direct: 1x1 / Linear / small-map layers)",
                  "attn": "attn_fwd / attn_bwd_dq / attn_bwd_dkv"}
 
@@ -337,7 +338,7 @@ def main():
                      "note": "achieved = EXECUTED MFMA flops / kernel time (HIP events around every launch of one profiled step); "
                              "frac = achieved / peak.  Winograd executes 4/9 (2-D F(2x2,3x3)) or 2/3 (1-D F(2,3)) of the direct convolution's flops: "
                              "`algorithmic` is the direct-convolution rate (SURVEY 8d's 213.9 GFLOP/image figures)."})
-        for kind, key in (("wino", "wino_1d"), ("igemm", "igemm_direct"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
+        for kind, key in (("wino", "wino_1d"), ("igemm", "igemm_direct"), ("wgrad_wino2", "wgrad_wino2d"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
             if kind in by and kind != dom_kind:
                 roof[key] = mfma_entry(kind)
         # whole step against the MFMA roof: every GEMM-shaped launch of the profiled step

@@ -100,11 +100,21 @@ int adm_pack_weight_wino2d(const float* w, float* wf, float* wb, int Co, int Ci,
 int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H, int W,
                         int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
 
+/* 2-D Winograd F(3x3, 2x2) weight gradient (conv_wgrad_wino.hip, MODE 2): 1.5x fewer MFMA flops than adm_conv_wgrad_wino.  H, W
+ * powers of two, H >= 2.  dwp2[Cout][4 ey][3 kx][Cin] holds the x-folded transform planes; adm_unpack_wgrad_wino2d applies the
+ * y half of G^T while scattering to OIHW (splits = 1, bws = dbias = NULL for the atomic path; the workspace form of
+ * adm_conv_wgrad_ws(wino = 2) otherwise). */
+int adm_conv_wgrad_wino2d(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx,
+                          int Cout, int lddy, int splits, hipStream_t stream);
+int adm_unpack_wgrad_wino2d(const float* wx, int splits, float* dw, int Co, int Ci, int Co_pad, int Ci_pad, int accumulate,
+                            const float* bws, float* dbias, hipStream_t stream);
+
 /* Deterministic weight gradients (bitwise reproducible backward; SURVEY.md section 5.2 "run twice, bit-compare").  The
  * kernels above combine their pixel-range splits with fp32 atomics.  Here split z writes its partial tile with plain stores
  * to ws[z][Cout][ks*ks][Cin] (and its bias partial to bws[z][Cout], bws may be NULL) and adm_unpack_wgrad_splits sums the
  * splits in a fixed order.  adm_conv_wgrad_plan returns the split count the launcher picks (>= 1) for the direct
- * (wino = 0) or Winograd F(3,2) (wino = 1: ks = 3, power-of-two H and W) kernel; pass it as `splits`. */
+ * (wino = 0), Winograd F(3,2) (wino = 1: ks = 3, power-of-two H and W) or 2-D F(3x3,2x2) (wino = 2; ws planes are then
+ * [Cout][12][Cin], see adm_conv_wgrad_wino2d) kernel; pass it as `splits`. */
 int adm_conv_wgrad_plan(int B, int H, int W, int Cin, int Cout, int ks, int up, int wino);
 int adm_conv_wgrad_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
                       int lddy, int ks, int up, int splits, int wino, hipStream_t stream);

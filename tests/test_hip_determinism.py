@@ -26,7 +26,7 @@ def ops(monkeypatch):
     return _ops
 
 
-@pytest.mark.parametrize("B,cin,cout,H,ks,up,qkv", [(8, 64, 96, 32, 3, False, False), (4, 96, 64, 16, 3, True, False),
+@pytest.mark.parametrize("B,cin,cout,H,ks,up,qkv", [(8, 64, 96, 32, 3, False, False), (4, 96, 64, 16, 3, True, False), (32, 64, 64, 16, 3, False, False),
                                                     (16, 128, 64, 8, 3, False, False), (8, 64, 192, 16, 1, False, True),
                                                     (3, 32, 3, 12, 3, False, False), (5, 768, 384, 1, 1, False, False)])
 def test_deterministic_weight_gradient_matches_and_repeats(ops, B, cin, cout, H, ks, up, qkv):

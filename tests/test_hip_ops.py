@@ -186,9 +186,18 @@ def test_conv_wgrad_winograd_op_level(ops, monkeypatch, B, cin, cout, H, W, up, 
     y = ops.conv2d(xd, wd, bd, None, up=up)
     (y * nhwc(pad_c(gy, cop))).sum().backward()
     kinds = [r[0] for r in ops.PROFILE]
-    assert "wgrad_wino" in kinds and "wgrad" not in kinds, kinds
+    # even-height, non-upsampled shapes take the 2-D F(3x3,2x2) form (conv_wgrad_wino.hip MODE 2), the others the 1-D F(3,2) form
+    assert kinds.count("wgrad_wino2" if (not up and H >= 2) else "wgrad_wino") == 1 and "wgrad" not in kinds, kinds
     close(wd.grad, wr.grad)
     close(bd.grad, br.grad)
+    monkeypatch.setattr(ops, "WINOGRAD2D", False)              # ... and the 1-D form on the same problem
+    wd2, bd2 = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    monkeypatch.setattr(ops, "PROFILE", [])
+    y2 = ops.conv2d(xd, wd2, bd2, None, up=up)
+    (y2 * nhwc(pad_c(gy, cop))).sum().backward()
+    assert [r[0] for r in ops.PROFILE].count("wgrad_wino") == 1
+    close(wd2.grad, wr.grad)
+    close(bd2.grad, br.grad)
 
 
 def test_linear_split_k_is_deterministic(ops):
