@@ -88,15 +88,13 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
       // dY rows 2ty (r0) and 2ty + 1 (r1): a_y = (r0, r0 + r1, r0 - r1, -r1)[ey]
       const unsigned ya = (pv && a_col != OOB) ? pix * (unsigned)p.lddy * 4u + a_col : OOB;
       const unsigned ystep = (unsigned)p.lddy * 4u, yrow = (unsigned)p.W * ystep;
+      // rows that a pass does not use are 'loaded' out of range (zeros, no memory traffic): ey = 0 uses r0 only, ey = 3 r1 only
+      const unsigned y0 = (ey != 3) ? ya : OOB, y1 = (ey != 0 && ya != OOB) ? ya + yrow : OOB;
       f32x4 t0[2], t1[2];
-      if (ey != 3) {
-        t0[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)ya, 0, 0));
-        t0[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(ya != OOB ? ya + ystep : OOB), 0, 0));
-      }
-      if (ey != 0) {
-        t1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(ya != OOB ? ya + yrow : OOB), 0, 0));
-        t1[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(ya != OOB ? ya + yrow + ystep : OOB), 0, 0));
-      }
+      t0[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y0, 0, 0));
+      t0[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y0 != OOB ? y0 + ystep : OOB), 0, 0));
+      t1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y1, 0, 0));
+      t1[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y1 != OOB ? y1 + ystep : OOB), 0, 0));
       // X rows 2ty - 1 + i: (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey], columns 2xp - 1 .. 2xp + 2
       const int iA = (ey == 0) ? 0 : 1, iB = (ey == 3) ? 3 : 2;
       const bool vA = pv && b_col != OOB && (iA != 0 || ty > 0), vB = pv && b_col != OOB && (iB != 3 || ty < (p.H >> 1) - 1);
@@ -110,10 +108,8 @@ __global__ __launch_bounds__(256) void wgrad_wino_kernel(WwP p) {
         u0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x0, (int)((vA && cv) ? xa + j * xstep : OOB), 0, 0));
         u1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x0, (int)((vB && cv) ? xb + j * xstep : OOB), 0, 0));
       }
-      if (ey == 0) { e[0] = t0[0]; e[1] = t0[1]; }
-      else if (ey == 1) { e[0] = t0[0] + t1[0]; e[1] = t0[1] + t1[1]; }
-      else if (ey == 2) { e[0] = t0[0] - t1[0]; e[1] = t0[1] - t1[1]; }
-      else { e[0] = -t1[0]; e[1] = -t1[1]; }
+      if (ey <= 1) { e[0] = t0[0] + t1[0]; e[1] = t0[1] + t1[1]; }      // (r0, r0 + r1, r0 - r1, -r1)[ey] with the unused row = 0
+      else { e[0] = t0[0] - t1[0]; e[1] = t0[1] - t1[1]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[j] = (ey == 1) ? u0[j] + u1[j] : (ey == 2) ? u1[j] - u0[j] : u0[j] - u1[j];
       return;
