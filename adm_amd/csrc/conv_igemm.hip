@@ -416,3 +416,14 @@ extern "C" int adm_conv_fwd_ws(const float* x, const float* wp, const float* bia
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
+
+// y[m][n] = sum_z ws[z][m][n] + bias[n] + res[m][n] in a fixed order: shared by the split-K paths of conv_wino2d.hip
+int adm_splitk_reduce(const float* ws, const float* bias, const float* res, float* y, long M, int N, int ldy, int ldr, int splitk,
+                      hipStream_t stream) {
+  const long total = M * (N / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, bias, res, y, M, N, ldy, ldr, splitk);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}

@@ -36,6 +36,7 @@ namespace {
 struct Wino2P {
   const float* x; const float* w; const float* bias; const float* res; float* y;
   int Mt, N, H, W, Hh, Wh, Cin, ldx, ldy, ldr, wrows, tilesN, xbytes, wbytes, plane;   // Mt = B * H/2 * W/2 tiles; plane = wrows * Cin
+  int splitk, chunks_per_split; float* ws;     // split-K over the input channels (small maps): partial outputs to ws[z][M][N]
 };
 
 typedef __attribute__((address_space(3))) void wino2_lds_void;
@@ -94,8 +95,15 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
     b_voff[i] = (n < p.wrows) ? (unsigned)(wid * p.plane + n * p.Cin + ls * 4) * 4u : OOB;
   }
 
-  const int chunks = p.Cin >> 4;                  // 16-channel chunks
-  const int KT = 4 * chunks;                      // four passes (ey) over K = Cin
+  // split-K (gridDim.y > 1): this workgroup reduces over the channel chunks [c_begin, c_begin + chunks) only and writes a raw
+  // partial tile (no bias / residual) to its slice of the workspace; splitk_reduce (conv_igemm.hip) sums the slices in order
+  const int c_begin = (p.splitk > 1) ? (int)blockIdx.y * p.chunks_per_split : 0;
+  const int chunks = (p.splitk > 1) ? min(p.chunks_per_split, (p.Cin >> 4) - c_begin) : (p.Cin >> 4);     // 16-channel chunks
+  const int KT = 4 * chunks;                      // four passes (ey) over this workgroup's K range
+  if (p.splitk > 1) {
+    p.y = p.ws + (long)blockIdx.y * ((long)p.Mt * 4) * p.N;
+    p.ldy = p.N; p.bias = nullptr; p.res = nullptr;
+  }
   int ld_ey = 0, ld_cc = 0;
   f32x4 dA[4], dB[4];
   int st_ey = 0;                                  // pass of the stage being LOADED (consumed by store_stage: selects the signs)
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wino2d_kernel(Wino2P p) {
         a_voff[1][j] = (vB && cv) ? a_base + (unsigned)(offB + (j - 1) * p.ldx * 4) : OOB;
       }
     }
-    const int soff = ld_cc << 6;                  // 16 floats = 64 bytes per chunk
+    const int soff = (c_begin + ld_cc) << 6;      // 16 floats = 64 bytes per chunk
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (W2_ABL & 1) { dA[j] = f32x4{1.f, 2.f, 3.f, (float)soff}; dB[j] = f32x4{0.5f, 0.25f, (float)j, 1.f}; continue; }
@@ -296,9 +304,26 @@ extern "C" int adm_pack_weight_wino2d(const float* w, float* wf, float* wb, int 
 }
 
 // y[B][H][W][ldy] = conv3x3(x[B][H][W][ldx], pad 1) (+ bias) (+ res); wq = adm_pack_weight_wino2d operand with `wrows` rows per
-// plane (>= N) and K = Cin columns.  H and W even; Cin % 16 == 0.
-extern "C" int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H,
-                                   int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream) {
+// plane (>= N) and K = Cin columns.  H and W even; Cin % 16 == 0.  ws (may be NULL) = workspace of ws_floats >=
+// adm_wino2d_splitk(...) * B*H*W*N floats: small launches then split K and reduce deterministically (fixed order).
+int adm_splitk_reduce(const float* ws, const float* bias, const float* res, float* y, long M, int N, int ldy, int ldr, int splitk,
+                      hipStream_t stream);       // conv_igemm.hip
+
+// Split count over the input channels for small launches: the 64-tile x 64-cout workgroups of an 8x8 map at batch 128 number
+// 192, for 512 resident slots.  Splits are chosen to fill the slots (whole rounds), keeping >= 4 chunks (64 channels) per split.
+extern "C" int adm_wino2d_splitk(int B, int H, int W, int Cin, int N) {
+  const long wgs = (long)adm_cdiv((long)B * (H / 2) * (W / 2), W2P) * adm_cdiv(N, W2N);
+  const int chunks = Cin >> 4;
+  if (wgs >= 384 || chunks < 8) return 1;
+  int s = (int)(512 / wgs);
+  if (s > chunks / 4) s = chunks / 4;
+  if (s > 4) s = 4;
+  return s < 2 ? 1 : s;
+}
+
+extern "C" int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, const float* res, float* y, float* ws,
+                                   long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                                   hipStream_t stream) {
   if (!x || !wq || !y || B <= 0 || H < 2 || W < 2 || (W & 1) || (H & 1)) return ADM_EINVAL;
   if ((Cin & 15) || (ldx & 3) || N <= 0 || wrows < N) return ADM_EINVAL;
   if (((uintptr_t)x | (uintptr_t)wq) & 15) return ADM_EINVAL;
@@ -310,6 +335,16 @@ extern "C" int adm_conv_fwd_wino2d(const float* x, const float* wq, const float*
   p.Mt = (int)Mt; p.N = N; p.H = H; p.W = W; p.Hh = H / 2; p.Wh = W / 2; p.Cin = Cin; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin;
   p.tilesN = adm_cdiv(N, W2N);
+  p.splitk = 1; p.chunks_per_split = 0; p.ws = nullptr;
+  const long wgs = (long)adm_cdiv(Mt, W2P) * p.tilesN;
+  const int sk = (ws && !(N & 3) && !(ldy & 3) && (!res || !(ldr & 3))) ? adm_wino2d_splitk(B, H, W, Cin, N) : 1;
+  if (sk > 1 && ws_floats >= (long)sk * Mt * 4 * N) {
+    const int chunks = Cin >> 4;
+    p.chunks_per_split = (chunks + sk - 1) / sk;
+    p.splitk = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    p.ws = ws;
+  }
+  (void)wgs;
   constexpr int smem = 2 * (4 * W2P + 4 * W2N) * W2K * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -319,7 +354,8 @@ extern "C" int adm_conv_fwd_wino2d(const float* x, const float* wq, const float*
     attr_set = true;
   }
   const long grid = (long)adm_cdiv(Mt, W2P) * p.tilesN;
-  hipLaunchKernelGGL(igemm_wino2d_kernel, dim3((unsigned)grid), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL(igemm_wino2d_kernel, dim3((unsigned)grid, p.splitk), dim3(256), smem, stream, p);
   ADM_CHECK_LAUNCH();
+  if (p.splitk > 1) return adm_splitk_reduce(ws, bias, res, y, Mt * 4, N, ldy, ldr, p.splitk, stream);
   return ADM_OK;
 }

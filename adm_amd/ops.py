@@ -299,7 +299,10 @@ def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None,
     """fp32 conv: 2-D Winograd F(2x2,3x3) kernel when `wq2` is given, 1-D F(2,3) when `wq`, else the direct implicit GEMM;
     small-M problems get the deterministic split-K path (workspace + fixed-order reduce)."""
     if wq2 is not None:
-        call("adm_conv_fwd_wino2d", ptr(x), ptr(wq2), ptr(bias), ptr(res), ptr(y), B, Ho, Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
+        sk = hip.lib().adm_wino2d_splitk(B, Ho, Wo, cin_p, n_p)
+        ws = _new((sk * B * Ho * Wo * n_p,), x) if sk > 1 else None       # small maps: split over the input channels, fixed-order reduce
+        call("adm_conv_fwd_wino2d", ptr(x), ptr(wq2), ptr(bias), ptr(res), ptr(y), ptr(ws), 0 if ws is None else ws.numel(), B, Ho, Wo,
+             cin_p, cin_p, n_p, n_p, n_p, n_p)
         return
     if wq is not None:
         call("adm_conv_fwd_wino_up" if up else "adm_conv_fwd_wino", ptr(x), ptr(wq), ptr(bias), ptr(res), ptr(y), B, Ho, Wo,

@@ -97,8 +97,10 @@ int adm_conv_wgrad_wino_up(const float* x, const float* dy, float* dwp, float* d
  * than adm_conv_fwd_wino; H and W even, Cin % 16 == 0.  wq = adm_pack_weight_wino2d operand: wf[16][Co_pad][Ci_pad] (forward)
  * or wb[16][Ci_pad][Co_pad] (data gradient, taps flipped), plane index ey * 4 + ex of U = G g G^T. */
 int adm_pack_weight_wino2d(const float* w, float* wf, float* wb, int Co, int Ci, int Co_pad, int Ci_pad, hipStream_t stream);
-int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, const float* res, float* y, int B, int H, int W,
-                        int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
+int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, const float* res, float* y, float* ws, long ws_floats,
+                        int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
+/* split count (>= 1) adm_conv_fwd_wino2d uses when given a workspace of that many B*H*W*N-float slices (small maps) */
+int adm_wino2d_splitk(int B, int H, int W, int Cin, int N);
 
 /* 2-D Winograd F(3x3, 2x2) weight gradient (conv_wgrad_wino.hip, MODE 2): 1.5x fewer MFMA flops than adm_conv_wgrad_wino.  H, W
  * powers of two, H >= 2.  dwp2[Cout][4 ey][3 kx][Cin] holds the x-folded transform planes; adm_unpack_wgrad_wino2d applies the

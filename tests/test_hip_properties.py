@@ -115,27 +115,30 @@ def test_sampler_step_fixed_point_and_range(ops):
     assert float(z.min()) >= 0.0 and float(z.max()) <= 1.0
 
 
+@pytest.mark.parametrize("two_d", [True, False])
 @pytest.mark.parametrize("B,H,cin,cout", [(128, 32, 192, 192), (128, 16, 768, 384), (128, 8, 384, 384)])
-def test_winograd_and_direct_kernels_agree_full_size(ops, monkeypatch, B, H, cin, cout):
-    """At BASELINE's sizes the 3x3 convs run through the Winograd F(2,3) / F(3,2) kernels; forward, data gradient, weight
-    gradient and bias gradient must agree with the direct implicit-GEMM kernels to fp32 rounding (different summation
-    orders, same arithmetic)."""
+def test_winograd_and_direct_kernels_agree_full_size(ops, monkeypatch, B, H, cin, cout, two_d):
+    """At BASELINE's sizes the 3x3 convs run through the Winograd kernels -- 2-D F(2x2,3x3) / F(3x3,2x2) by default (incl. the
+    split-K small-map launches), 1-D F(2,3) / F(3,2) with ADM_WINOGRAD2D=0; forward, data gradient, weight gradient and bias
+    gradient must agree with the direct implicit-GEMM kernels to fp32 rounding (different summation orders, same arithmetic)."""
     x = rnd((B, H, H, cin), 11)
     w0 = rnd((cout, cin, 3, 3), 12, 1 / math.sqrt(cin * 9))
     b0 = rnd((cout,), 13)
     gy = rnd((B, H, H, cout), 14)
     out = {}
+    monkeypatch.setattr(ops, "WINOGRAD2D", two_d)
     for mode in (True, False):
         monkeypatch.setattr(ops, "WINOGRAD", mode)
         xd = x.clone().requires_grad_(True)
         w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
         y = ops.conv2d(xd, w, b)
-        assert (w._adm_packed.wf is not None) == mode
+        pk = w._adm_packed
+        assert (pk.w2f is not None) == (mode and two_d) and (pk.wf is not None) == (mode and not two_d)
         (y * gy).sum().backward()
         out[mode] = (y.detach(), xd.grad, w.grad, b.grad)
     for got, want, name in zip(out[True], out[False], ("y", "dx", "dw", "db")):
         err = float((got - want).abs().max() / want.abs().max())
-        assert err <= 2e-5, (name, err)
+        assert err <= (4e-5 if two_d else 2e-5), (name, err)
 
 
 def test_full_model_training_step_winograd_vs_direct(ops, monkeypatch):

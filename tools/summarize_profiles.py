@@ -15,6 +15,10 @@ def load(pattern):
 
 
 def cls(n):
+    if "wgrad_wino_kernel<2>" in n:
+        return "wgrad_wino2d"
+    if "igemm_wino2d" in n:
+        return "wino2d"
     return ("wgrad_wino" if "wgrad_wino" in n else "wgrad" if "wgrad" in n else "wino" if "wino" in n else "igemm" if "igemm" in n else "attn" if "attn" in n else "gn" if "::gn_" in n
             else "other")
 
