@@ -1,0 +1,46 @@
+// Diagnostic micro-benchmark for the split-bf16 2-D Winograd kernel (not part of the product).
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DX6_ACC2=0] tools/bench_wino2d_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bx && LD_LIBRARY_PATH=adm_amd /tmp/bx
+#include "../adm_amd/csrc/conv_wino2d_x6.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+static void run(int B, int H, int Cin, int N, bool check) {
+  size_t nx = (size_t)B * H * H * Cin, nw = (size_t)16 * N * Cin, ny = (size_t)B * H * H * N;
+  std::vector<float> hx(nx), hw(nw);
+  for (auto& v : hx) v = (rand() / (float)RAND_MAX) * 2 - 1;
+  for (auto& v : hw) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.02f;
+  float *x, *w, *y, *y2; void* w6;
+  hipMalloc(&x, nx * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, ny * 4); hipMalloc(&y2, ny * 4); hipMalloc(&w6, nw * 6);
+  hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
+  adm_split3_bf16(w, w6, (long)N * Cin, 16, 0);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
+  hipDeviceSynchronize();
+  const int reps = 20;
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  double fl = 2.0 * B * H * H * (double)N * 9 * Cin;
+  printf("x6 acc2=%d B=%d H=%d Cin=%d N=%d: %.3f ms  %.1f TFLOP/s algorithmic", X6_ACC2, B, H, Cin, N, ms, fl / ms / 1e9);
+  if (check) {
+    adm_conv_fwd_wino2d(x, w, nullptr, nullptr, y2, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
+    std::vector<float> a(ny), b(ny);
+    hipMemcpy(a.data(), y, ny * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), y2, ny * 4, hipMemcpyDeviceToHost);
+    double mx = 0, sc = 0;
+    for (size_t i = 0; i < ny; ++i) { mx = fmax(mx, fabs((double)a[i] - b[i])); sc = fmax(sc, fabs((double)b[i])); }
+    printf("   max|x6 - f32 kernel| = %.3e (max|y| %.3e)", mx, sc);
+  }
+  printf("\n");
+  hipFree(x); hipFree(w); hipFree(y); hipFree(y2); hipFree(w6);
+}
+int main() {
+  run(2, 8, 32, 64, true);
+  run(128, 32, 384, 384, true);
+  run(128, 32, 192, 192, false);
+  run(128, 16, 384, 384, false);
+  run(128, 16, 768, 384, false);
+  run(128, 8, 384, 384, false);
+  return 0;
+}
