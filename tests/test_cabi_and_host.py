@@ -27,6 +27,11 @@ def test_library_exports_every_declared_symbol():
     assert sorted(hip.EXPORTS) == declared, set(hip.EXPORTS) ^ set(declared)
     assert lib.adm_version() >= 1
     assert lib.adm_gn_splits(1024, 192) == 16 and lib.adm_gn_splits(16, 384) == 1
+    # the ctypes argument table has exactly one entry per parameter of the C declaration
+    for m in re.finditer(r"^(?:int|long)\s+(adm_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.M | re.S):
+        name, params = m.group(1), m.group(2).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert len(hip._SIGS[name]) == n, f"{name}: header has {n} parameters, adm_amd/hip.py::_SIGS has {len(hip._SIGS[name])}"
 
 
 def test_missing_library_fails_loudly(monkeypatch):
