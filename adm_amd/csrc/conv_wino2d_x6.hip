@@ -6,28 +6,38 @@
 // the f32 accumulator, so
 //     a b = a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0) + O(2^-24 |a b|)
 // -- six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for K = 16) replace eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 2.67x less
-// matrix-pipe time at f32 accuracy.  The five small products are summed in their own accumulator chain (started from C = 0) and
-// added to the running sum once per K step with one f32 add: the accumulator sees ONE matrix add per 16 channels (not six), which
-// measures BELOW the f32 MFMA's own rounding error against an fp64 reference on both zero-mean and all-positive data
-// (tools/bf16x6_probe.hip; tests/test_hip_ops.py::test_conv_x6_error_vs_fp64).
+// matrix-pipe time at f32 accuracy (tools/bf16x6_probe.hip: the six products in a short accumulator chain started from C = 0
+// and added to the running sum with one f32 add measure BELOW the f32 MFMA's own rounding error against fp64, on zero-mean and
+// on all-positive data; six truncating matrix adds into one long-running accumulator would be 3x worse on the latter).
 //
-// Everything else is conv_wino2d.hip's algorithm (same transforms, same pass structure: ey a loop in time, four ex accumulator
-// tiles per wave, output rows folded in registers).  What changes is the balance -- the matrix pipe is no longer the bound, the data
-// path is -- and with it the shape:
-//   * workgroup = 512 threads = 8 waves (4 x 2), 128 tiles x 64 couts, ONE per CU: the split operands take 6 bytes per element
-//     (A 48 KB + B 24 KB per stage, double buffered = 144 KB of the 160 KB LDS);
-//   * A: thread = (tile, 16-byte channel quad): 2 rows x 4 pixels raw buffer loads (range check = zero padding), y combination and
-//     B^T along x in f32 exactly as before, then the three-term split (and / sub / and / sub per element, v_perm packing) and
-//     twelve ds_write_b64 into the [ex plane][term] images.  Rows are 32 bytes (16 bf16 channels): both the 8-byte writes and the
-//     16-byte fragment reads of a wave cover contiguous LDS, conflict-free without a swizzle;
-//   * B: weights are split once per optimiser step at pack time (adm_split3_bf16) into Wq6[ey][ex][term][n][cin] and go straight
-//     to LDS by LDS-DMA (24 one-KB wave instructions per stage, three per wave).
+// The algorithm is conv_wino2d.hip's (same transforms, four ex accumulator tiles per wave, output rows folded in registers);
+// the loop order and the division of labour are not:
+//   * the matrix pipe is no longer the bound, the data path is.  The f32 kernel's stages are as long as a global load takes
+//     (every barrier of a __syncthreads also drains vmcnt), which the 2048-cycle f32 MFMA phase used to cover; a 768-cycle bf16
+//     phase does not.  So the roles are split (512 threads, one workgroup per CU):
+//       - waves 4-7 PRODUCE the A operand: thread = (tile, 16-byte channel quad) loads the whole 4 x 4 input patch of a
+//         16-channel chunk ONCE (16 raw buffer loads, range check = zero padding; the f32 kernel loads 2 rows per pass = 32) into
+//         one of two register sets -- the next chunk's loads are in flight while the four ey sub-stages of the current chunk
+//         are transformed (y combination and B^T along x in f32 exactly as before), split into three bf16 terms (and / sub /
+//         and / sub per element, v_perm packing) and written to LDS (twelve ds_write_b64 per sub-stage);
+//       - waves 0-3 CONSUME: 32 tiles x 32 couts each, six MFMAs per ex plane from C = 0, and the x / y output transforms are
+//         applied to the fresh products of EVERY sub-stage with f32 adds into the output rows held in registers.  The running
+//         sums therefore see one rounded f32 add per 16 channels instead of a truncating matrix add per product: measured
+//         against fp64 the error is at or below the f32 MFMA kernel's (tests/test_hip_ops.py::test_conv_x6_error_vs_fp64).
+//         These waves also issue the weight DMA (their only global accesses: the explicit vmcnt wait before a barrier
+//         never touches the producers' prefetch);
+//       - barriers are s_barrier with LDS-scoped fences (lgkmcnt only): the producers' loads stay in flight across them.
+//   * LDS: A[2][4 ex][3 terms][64 tiles][16 ch] bf16 (2 x 24 KB) + B[3][4 ex][3 terms][64 couts][16 ch] (3 x 24 KB; weights are
+//     split once per optimiser step at pack time, adm_split3_bf16, and arrive by LDS-DMA two sub-stages ahead).  Rows are 32
+//     bytes with the two 16-byte halves of rows 8-15 (mod 16) swapped, so that the 16 lanes of a fragment-read group hit all 64 banks
+//     (un-swizzled: 40 % of the LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).
 // Replaces F.conv2d of Conv2d.forward and its autograd data gradient (/root/reference/unet/uncond_unet.py:98-110).
 #include "common.h"
 #include "../../include/adm_hip.h"
+#include <type_traits>
 
-#ifndef X6_ACC2
-#define X6_ACC2 1     // 1: small products in their own chain (see above); 0: all six into the running accumulator
+#ifndef X6_ABL
+#define X6_ABL 0     // diagnostic builds (tools/bench_wino2d_x6.cpp): 1 no A global loads, 2 no A transform / split / LDS stores, 4 no B DMA, 8 no MFMAs, 16 no LDS fragment reads
 #endif
 
 namespace {
@@ -42,33 +52,88 @@ typedef __attribute__((address_space(3))) void x6_lds_void;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int X6P_T = 128, X6N = 64, X6K = 16;     // tiles x couts x K step
-constexpr int X6_A_STAGE = 4 * 3 * X6P_T * X6K;    // bf16 elements per A stage
+constexpr int X6P_T = 64, X6N = 64, X6K = 16;      // tiles x couts x K step
+constexpr int X6_A_STAGE = 4 * 3 * X6P_T * X6K;    // bf16 elements per A sub-stage image (24 KB)
 constexpr int X6_B_STAGE = 4 * 3 * X6N * X6K;
+constexpr int X6_RA = 2, X6_RB = 3;                // ring depths
 
-// v = v0 + v1 + v2 exactly, each term a bf16 (returned as the packed top halves of four lanes' worth: two dwords per term)
-__device__ __forceinline__ void split3_pack(const f32x4 v, u32x2& t0, u32x2& t1, u32x2& t2) {
-  unsigned u[4], m[4], l[4];
+// LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), NOT for its global loads
+__device__ __forceinline__ void x6_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// a - b on a register pair in one instruction (the compiler packs f32 adds but scalarises subtractions)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+  const f32x2 lo = pk_sub(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+__device__ __forceinline__ f32x16 sub16(f32x16 a, f32x16 b) {
+  f32x16 r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    u[i] = __float_as_uint(v[i]);
-    const float r = v[i] - __uint_as_float(u[i] & 0xFFFF0000u);
-    m[i] = __float_as_uint(r);
-    const float r2 = r - __uint_as_float(m[i] & 0xFFFF0000u);
-    l[i] = __float_as_uint(r2);
+  for (int i = 0; i < 16; i += 2) {
+    const f32x2 t = pk_sub(f32x2{a[i], a[i + 1]}, f32x2{b[i], b[i + 1]});
+    r[i] = t[0]; r[i + 1] = t[1];
   }
-  t0 = u32x2{__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u)};
-  t1 = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
-  t2 = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+  return r;
+}
+
+// v = v0 + v1 + v2 exactly, each term a bf16 (packed top halves: two dwords per term for the four channels)
+__device__ __forceinline__ void split3_pack(const f32x4 v, u32x2& t0, u32x2& t1, u32x2& t2) {
+  f32x4 h, mh;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) h[i] = __uint_as_float(__float_as_uint(v[i]) & 0xFFFF0000u);
+  const f32x4 r = sub4(v, h);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mh[i] = __uint_as_float(__float_as_uint(r[i]) & 0xFFFF0000u);
+  const f32x4 r2 = sub4(r, mh);
+  t0 = u32x2{__builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u),
+             __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u)};
+  t1 = u32x2{__builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u),
+             __builtin_amdgcn_perm(__float_as_uint(r[3]), __float_as_uint(r[2]), 0x07060302u)};
+  t2 = u32x2{__builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u),
+             __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u)};
+}
+
+// producer: one ey sub-stage of the chunk held in raw[row][pixel] -> the [ex][term] images of A slot `la`
+template <int EY>
+__device__ __forceinline__ void x6_produce(const f32x4 (&raw)[4][4], unsigned short* la) {
+  if (X6_ABL & 2) return;
+  f32x4 e[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)      // pass ey combines input rows: 0: r0 - r2   1: r1 + r2   2: r2 - r1   3: r1 - r3
+    e[j] = EY == 0 ? sub4(raw[0][j], raw[2][j]) : EY == 1 ? raw[1][j] + raw[2][j] : EY == 2 ? sub4(raw[2][j], raw[1][j]) : sub4(raw[1][j], raw[3][j]);
+  const f32x4 v[4] = {sub4(e[0], e[2]), e[1] + e[2], sub4(e[2], e[1]), sub4(e[1], e[3])};
+#pragma unroll
+  for (int ex = 0; ex < 4; ++ex) {
+    u32x2 t0, t1, t2;
+    split3_pack(v[ex], t0, t1, t2);
+    *reinterpret_cast<u32x2*>(la + (ex * 3 + 0) * X6P_T * X6K) = t0;
+    *reinterpret_cast<u32x2*>(la + (ex * 3 + 1) * X6P_T * X6K) = t1;
+    *reinterpret_cast<u32x2*>(la + (ex * 3 + 2) * X6P_T * X6K) = t2;
+  }
 }
 
 __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem6[];
-  unsigned short* As = smem6;                      // [2][4 ex][3 terms][X6P_T][X6K]
-  unsigned short* Bs = smem6 + 2 * X6_A_STAGE;     // [2][4 ex][3 terms][X6N][X6K]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int lr = lane & 31, lh = lane >> 5;
+  unsigned short* As = smem6;                          // [X6_RA][4 ex][3 terms][X6P_T][X6K]
+  unsigned short* Bs = smem6 + X6_RA * X6_A_STAGE;     // [X6_RB][4 ex][3 terms][X6N][X6K]
+  const int tid = threadIdx.x, lane = tid & 63, hw_wid = tid >> 6;
+#ifdef X6_INTERLEAVE_ROLES
+  const bool producer = hw_wid & 1;
+  const int wid = hw_wid >> 1;                         // role-local wave index 0..3
+#else
+  const bool producer = hw_wid >= 4;
+  const int wid = hw_wid & 3;
+#endif
   int bid = blockIdx.x;
   {   // XCD-aware bijective remap, m-fastest inside an n-tile (see conv_igemm.hip)
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -77,176 +142,183 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   const int tilesM = gridDim.x / p.tilesN;
   const int tm = bid % tilesM, tn = bid / tilesM;
   const int mt0 = tm * X6P_T, n0 = tn * X6N;
-
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, p.wbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
 
-  // ---- A loader: this thread owns tile `pl` and channel quad `aq` of every stage
-  const int pl = tid >> 2, aq = tid & 3;
-  unsigned a_base = 0;            // byte offset of pixel (b, 2ty, 2xp), channel quad aq
-  unsigned colmask = 0;           // bit j: column 2xp - 1 + j is inside the image
-  unsigned rowmask = 0;           // bit i: row 2ty - 1 + i is inside the image
-  {
-    const int t = mt0 + pl;
-    if (t < p.Mt) {
-      const int xp = t % p.Wh;
-      const int u = t / p.Wh;
-      const int ty = u % p.Hh, b = u / p.Hh;
-      a_base = (unsigned)((((long)b * p.H + 2 * ty) * p.W + 2 * xp) * p.ldx + aq * 4) * 4u;
-      colmask = (xp > 0 ? 1u : 0u) | 6u | (2 * xp + 2 < p.W ? 8u : 0u);
-      rowmask = (ty > 0 ? 1u : 0u) | 6u | (2 * ty + 2 < p.H ? 8u : 0u);
-    }
-  }
-  unsigned a_voff[2][4];          // [row A / row B of the current pass][pixel j]
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a_voff[r][j] = OOB;
-
-  // ---- B loader (LDS-DMA): 24 one-KB instructions per stage = (ex, term) image pt x 32-row half; wave w issues q = 3w .. 3w+2.
-  // Lane l of an instruction covers row (q & 1) * 32 + (l >> 1), 16-byte half (l & 1) of the 32-byte row.
-  unsigned b_voff[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int q = wid * 3 + i, pt = q >> 1;
-    const int row = (q & 1) * 32 + (lane >> 1);
-    const int n = n0 + row;
-    b_voff[i] = (n < p.wrows) ? (unsigned)(((long)pt * p.plane + (long)n * p.Cin + (lane & 1) * 8) * 2) : OOB;
-  }
-
   const int c_begin = (p.splitk > 1) ? (int)blockIdx.y * p.chunks_per_split : 0;
-  const int chunks = (p.splitk > 1) ? min(p.chunks_per_split, (p.Cin >> 4) - c_begin) : (p.Cin >> 4);     // 16-channel chunks
-  const int KT = 4 * chunks;                      // four passes (ey) over this workgroup's K range
+  const int chunks = (p.splitk > 1) ? min(p.chunks_per_split, (p.Cin >> 4) - c_begin) : (p.Cin >> 4);     // 16-channel chunks (even)
+  const int S = 4 * chunks;                           // sub-stages: (chunk, ey), ey fastest
+
+  if (producer) {
+    // ================================================================ producer waves: A operand
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
+    const int ptid = wid * 64 + lane;
+    const int pl = ptid >> 2, aq = ptid & 3;          // tile, channel quad
+    unsigned voff[4][4];                              // [row i = 2ty - 1 + i][pixel j = 2xp - 1 + j]
+    {
+      const int t = mt0 + pl;
+      unsigned a_base = 0, colmask = 0, rowmask = 0;
+      if (t < p.Mt) {
+        const int xp = t % p.Wh;
+        const int u = t / p.Wh;
+        const int ty = u % p.Hh, b = u / p.Hh;
+        a_base = (unsigned)((((long)b * p.H + 2 * ty) * p.W + 2 * xp) * p.ldx + aq * 4) * 4u;
+        colmask = (xp > 0 ? 1u : 0u) | 6u | (2 * xp + 2 < p.W ? 8u : 0u);
+        rowmask = (ty > 0 ? 1u : 0u) | 6u | (2 * ty + 2 < p.H ? 8u : 0u);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          voff[i][j] = (((rowmask >> i) & 1u) && ((colmask >> j) & 1u))
+                           ? a_base + (unsigned)(((i - 1) * p.W + (j - 1)) * p.ldx * 4) : OOB;
+    }
+    auto load_chunk = [&](f32x4 (&raw)[4][4], int c) {
+      const int soff = (c_begin + c) << 6;            // 16 floats = 64 bytes per chunk
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          raw[i][j] = (X6_ABL & 1) ? f32x4{1.f, 2.f, (float)soff, (float)j}
+                                   : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[i][j], soff, 0));
+    };
+    // rows are 32 bytes; a 16-lane group of a fragment read covers 16 rows at one 16-byte half, i.e. only half of the banks, unless
+    // the halves of rows 8-15 (mod 16) are swapped: physical half = logical half ^ ((row >> 3) & 1), for A and B alike
+    unsigned short* la0 = As + pl * X6K + ((((aq >> 1) ^ (pl >> 3)) & 1) << 3) + (aq & 1) * 4;
+    unsigned short* la1 = la0 + X6_A_STAGE;
+    f32x4 rawA[4][4], rawB[4][4];
+    load_chunk(rawA, 0);
+    // barrier t separates "A(t) written" from compute(t); A(t) goes to slot t & 1 (sub-stage parity = ey parity)
+    for (int c = 0; c < chunks; c += 2) {
+      // the loads of the NEXT chunk are issued here, before this chunk's four sub-stages (sched_barrier: the scheduler would
+      // otherwise sink them to their first use; the last iteration re-reads its own chunk instead of branching)
+      load_chunk(rawB, c + 1);                        // chunks is even: c + 1 always exists
+      __builtin_amdgcn_sched_barrier(0);
+      x6_produce<0>(rawA, la0); x6_barrier();
+      x6_produce<1>(rawA, la1); x6_barrier();
+      x6_produce<2>(rawA, la0); x6_barrier();
+      x6_produce<3>(rawA, la1); x6_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(rawA, min(c + 2, chunks - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      x6_produce<0>(rawB, la0); x6_barrier();
+      x6_produce<1>(rawB, la1); x6_barrier();
+      x6_produce<2>(rawB, la0); x6_barrier();
+      x6_produce<3>(rawB, la1); x6_barrier();
+    }
+    return;
+  }
+
+  // ================================================================== consumer waves: weight DMA, MFMA, output transform
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, p.wbytes, 0x00020000);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
   if (p.splitk > 1) {
     p.y = p.ws + (long)blockIdx.y * ((long)p.Mt * 4) * p.N;
     p.ldy = p.N; p.bias = nullptr; p.res = nullptr;
   }
-  int ld_ey = 0, ld_cc = 0;
-  f32x4 dA[4], dB[4];
-  int st_ey = 0;                                  // pass of the stage being LOADED (consumed by store_stage: selects the signs)
-  auto issue_stage = [&](int buf) {               // global -> registers (A), global -> LDS (B) for the NEXT stage
-    if (ld_cc == 0) {
-      // pass ey combines input rows (iA, iB) of the 4-row patch: 0: +r0 -r2   1: +r1 +r2   2: -r1 +r2   3: +r1 -r3
-      const int iA = (ld_ey == 0) ? 0 : 1, iB = (ld_ey == 3) ? 3 : 2;
-      const bool vA = (rowmask >> iA) & 1u, vB = (rowmask >> iB) & 1u;
-      const int offA = (iA - 1) * p.W * p.ldx * 4, offB = (iB - 1) * p.W * p.ldx * 4;
+  // B loader (LDS-DMA): 24 one-KB instructions per sub-stage = (ex, term) image pt x 32-row half; wave w issues q = 6w .. 6w+5.
+  // Lane l of an instruction covers row (q & 1) * 32 + (l >> 1), 16-byte half (l & 1) of the 32-byte row.
+  unsigned b_voff[6];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool cv = (colmask >> j) & 1u;
-        a_voff[0][j] = (vA && cv) ? a_base + (unsigned)(offA + (j - 1) * p.ldx * 4) : OOB;
-        a_voff[1][j] = (vB && cv) ? a_base + (unsigned)(offB + (j - 1) * p.ldx * 4) : OOB;
-      }
-    }
-    const int cidx = c_begin + ld_cc;
-    const int soff = cidx << 6;                   // 16 floats = 64 bytes per chunk
+  for (int i = 0; i < 6; ++i) {
+    const int q = wid * 6 + i, pt = q >> 1;
+    const int row = (q & 1) * 32 + (lane >> 1);
+    const int n = n0 + row;
+    const int half = (lane ^ (row >> 3)) & 1;           // logical half stored at physical half (lane & 1)
+    b_voff[i] = (n < p.wrows) ? (unsigned)(((long)pt * p.plane + (long)n * p.Cin + half * 8) * 2) : OOB;
+  }
+  auto issue_b = [&](int t) {                         // weights of sub-stage t -> ring slot t % 3
+    const int c = t >> 2, ey = t & 3;
+    const int kb = (ey * 12 * p.plane) * 2 + ((c_begin + c) << 5);   // ey block of twelve [ex][term] images; 32 bytes per chunk
+    unsigned short* lb = Bs + (t % X6_RB) * X6_B_STAGE + (wid * 6) * 512;       // 512 elements = one KB per instruction
+    if (X6_ABL & 4) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      dA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[0][j], soff, 0));
-      dB[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[1][j], soff, 0));
-    }
-    st_ey = ld_ey;
-    const int kb = (ld_ey * 12 * p.plane) * 2 + (cidx << 5);       // (ey) block of twelve [ex][term] images; 16 bf16 = 32 bytes per chunk
-    unsigned short* lb = Bs + buf * X6_B_STAGE + (wid * 3) * 512;  // 512 elements = one KB per instruction
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 6; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (x6_lds_void*)(lb + i * 512), 16, (int)b_voff[i], kb, 0, 0);
-    if (++ld_cc == chunks) { ld_cc = 0; ++ld_ey; }
-  };
-  auto store_stage = [&](int buf) {               // y combination, B^T along x (f32), three-term split, into the [ex][term] images
-    f32x4 e[4];
-    if (st_ey == 1) {                             // wave-uniform: one add / sub per element instead of a multiply-add pair
-#pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = dA[j] + dB[j];
-    } else if (st_ey == 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = dB[j] - dA[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = dA[j] - dB[j];
-    }
-    unsigned short* la = As + buf * X6_A_STAGE + pl * X6K + aq * 4;
-    const f32x4 v[4] = {e[0] - e[2], e[1] + e[2], e[2] - e[1], e[1] - e[3]};
-#pragma unroll
-    for (int ex = 0; ex < 4; ++ex) {
-      u32x2 t0, t1, t2;
-      split3_pack(v[ex], t0, t1, t2);
-      *reinterpret_cast<u32x2*>(la + (ex * 3 + 0) * X6P_T * X6K) = t0;
-      *reinterpret_cast<u32x2*>(la + (ex * 3 + 1) * X6P_T * X6K) = t1;
-      *reinterpret_cast<u32x2*>(la + (ex * 3 + 2) * X6P_T * X6K) = t2;
-    }
   };
 
-  f32x16 acc[4];
-  f32x16 Y[2][2];                                 // [output row][output column of the pair]
+  f32x16 Y[2][2];                                     // [output row][output column of the pair]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) Y[a][b][r] = 0.f;
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+  const int a_foff = (wm * 32 + lr) * X6K + ((lh ^ (lr >> 3)) & 1) * 8;   // fragment: row = tile / cout, 8 bf16 = 16 bytes at k = 8 (lane >> 5)
+  const int b_foff = (wn * 32 + lr) * X6K + ((lh ^ (lr >> 3)) & 1) * 8;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  const int a_foff = (wm * 32 + lr) * X6K + lh * 8;       // fragment: row = tile, 8 bf16 = 16 bytes at k = 8 (lane >> 5)
-  const int b_foff = (wn * 32 + lr) * X6K + lh * 8;
-
-  issue_stage(0);
-  store_stage(0);
-  __syncthreads();
-  int cc = 0, ey = 0;                             // (chunk, pass) of the stage being COMPUTED
-  for (int s = 0; s < KT; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < KT) issue_stage(buf ^ 1);
-    const unsigned short* Ab = As + buf * X6_A_STAGE + a_foff;
-    const unsigned short* Bb = Bs + buf * X6_B_STAGE + b_foff;
+  // one sub-stage: wait for the weights of t (issued two sub-stages ago; only B(t+1)'s six instructions may still be in flight),
+  // barrier (plain s_barrier + explicit counters: a release fence would drain the weight prefetch, vmcnt(0)), issue B(t+2),
+  // 24 MFMAs, output transform with this sub-stage's compile-time signs
+  auto sub_stage = [&](int t, auto ey_c) {
+    constexpr int ey = decltype(ey_c)::value;
+    if (t + 1 < S) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 2 < S) issue_b(t + 2);
+    const unsigned short* Ab = As + (ey & 1) * X6_A_STAGE + a_foff;
+    const unsigned short* Bb = Bs + (t % X6_RB) * X6_B_STAGE + b_foff;
+    // software pipeline over the four ex planes: the fragments of plane xi+1 are read and its six MFMAs issued before the x output
+    // transform (A^T: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3) consumes plane xi, so the adds run under the next plane's MFMAs and at
+    // most two planes' fragments and products are live
+    bf16x8 fa[2][3], fb[2][3];
+    auto load_frag = [&](int xi, int s) {
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi) {
-      bf16x8 a[3], b[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab + (xi * 3 + t) * X6P_T * X6K));
-        b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb + (xi * 3 + t) * X6N * X6K));
+      for (int k = 0; k < 3; ++k) {
+        if (X6_ABL & 16) {
+          fa[s][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, (unsigned)t, 0x3f803f80u, (unsigned)xi});
+          fb[s][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f003f00u, (unsigned)k, 0x3f003f00u, (unsigned)lane});
+          continue;
+        }
+        fa[s][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab + (xi * 3 + k) * X6P_T * X6K));
+        fb[s][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb + (xi * 3 + k) * X6N * X6K));
       }
-#if X6_ACC2
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], zero, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[xi], 0, 0, 0);
-      acc[xi] += c;
-#else
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[xi], 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[xi], 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[xi], 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[xi], 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[xi], 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[xi], 0, 0, 0);
-#endif
-    }
-    if (s + 1 < KT) store_stage(buf ^ 1);         // the other buffer was last read in stage s-1: every wave passed its barrier
-    if (++cc == chunks) {
-      // end of pass ey: A^T along x, then fold into the output rows (A^T along y: row 0 = Z0 + Z1 + Z2, row 1 = Z1 - Z2 - Z3)
-      cc = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m1 = acc[1][r], m2 = acc[2][r];
-        const float z0 = acc[0][r] + m1 + m2, z1 = m1 - m2 - acc[3][r];
-        if (ey <= 2) { Y[0][0][r] += z0; Y[0][1][r] += z1; }
-        if (ey == 1) { Y[1][0][r] += z0; Y[1][1][r] += z1; }
-        if (ey >= 2) { Y[1][0][r] -= z0; Y[1][1][r] -= z1; }
+    };
+    auto six = [&](int s) -> f32x16 {
+      if (X6_ABL & 8) {
+        f32x16 c = zero;
+        c[0] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fa[s][0])[0] ^ __builtin_bit_cast(u32x4, fb[s][2])[1]);
+        c[5] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fa[s][1])[2] ^ __builtin_bit_cast(u32x4, fb[s][1])[3]);
+        c[9] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fa[s][2])[0] ^ __builtin_bit_cast(u32x4, fb[s][0])[0]);
+        return c;
       }
-#pragma unroll
-      for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-      ++ey;
-    }
-    __syncthreads();
+      f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][2], zero, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][2], fb[s][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fb[s][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fb[s][0], c, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][0], c, 0, 0, 0);
+    };
+    load_frag(0, 0);
+    load_frag(1, 1);
+    f32x16 z0 = six(0);                       // m0
+    __builtin_amdgcn_sched_barrier(0);
+    load_frag(2, 0);
+    f32x16 m1 = six(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frag(3, 1);
+    f32x16 m2 = six(0);
+    z0 += m1;
+    f32x16 z1 = sub16(m1, m2);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 m3 = six(1);
+    z0 += m2;
+    __builtin_amdgcn_sched_barrier(0);
+    z1 = sub16(z1, m3);
+    if (ey <= 2) { Y[0][0] += z0; Y[0][1] += z1; }
+    if (ey == 1) { Y[1][0] += z0; Y[1][1] += z1; }
+    if (ey >= 2) { Y[1][0] = sub16(Y[1][0], z0); Y[1][1] = sub16(Y[1][1], z1); }
+    // pin the output transform inside its sub-stage (left alone, the compiler batches the transforms of four sub-stages at the loop
+    // top and spills for it)
+    asm volatile("" : "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]), "+v"(Y[1][1]));
+  };
+  issue_b(0);
+  issue_b(1);
+  for (int t = 0; t < S; t += 4) {
+    sub_stage(t, std::integral_constant<int, 0>{});
+    sub_stage(t + 1, std::integral_constant<int, 1>{});
+    sub_stage(t + 2, std::integral_constant<int, 2>{});
+    sub_stage(t + 3, std::integral_constant<int, 3>{});
   }
 
   // ---- epilogue.  C/D layout col = lane&31 (cout), row = (r&3) + 8 (r>>2) + 4 (lane>>5) (tile)
@@ -310,7 +382,7 @@ extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const flo
                                       long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                                       hipStream_t stream) {
   if (!x || !wq6 || !y || B <= 0 || H < 2 || W < 2 || (W & 1) || (H & 1)) return ADM_EINVAL;
-  if ((Cin & 15) || (ldx & 3) || N <= 0 || wrows < N) return ADM_EINVAL;
+  if ((Cin & 31) || (ldx & 3) || N <= 0 || wrows < N) return ADM_EINVAL;      // an even number of 16-channel chunks
   if (((uintptr_t)x | (uintptr_t)wq6) & 15) return ADM_EINVAL;
   X6P p;
   p.x = x; p.w = static_cast<const unsigned short*>(wq6); p.bias = bias; p.res = res; p.y = y;
@@ -324,11 +396,11 @@ extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const flo
   const int sk = (ws && !(N & 3) && !(ldy & 3) && (!res || !(ldr & 3))) ? adm_wino2d_x6_splitk(B, H, W, Cin, N) : 1;
   if (sk > 1 && ws_floats >= (long)sk * Mt * 4 * N) {
     const int chunks = Cin >> 4;
-    p.chunks_per_split = (chunks + sk - 1) / sk;
+    p.chunks_per_split = ((chunks + sk - 1) / sk + 1) & ~1;        // the producer double-buffers chunk pairs
     p.splitk = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     p.ws = ws;
   }
-  constexpr int smem = 2 * (X6_A_STAGE + X6_B_STAGE) * (int)sizeof(unsigned short);
+  constexpr int smem = (X6_RA * X6_A_STAGE + X6_RB * X6_B_STAGE) * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
@@ -348,8 +420,8 @@ extern "C" int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N) {
   const long wgs = (long)adm_cdiv((long)B * (H / 2) * (W / 2), X6P_T) * adm_cdiv(N, X6N);
   const int chunks = Cin >> 4;
   if (wgs >= 192 || chunks < 8) return 1;
-  int s = (int)(256 / wgs);
+  int s = (int)(768 / wgs);                 // up to three rounds of one workgroup per CU
   if (s > chunks / 4) s = chunks / 4;
-  if (s > 4) s = 4;
+  if (s > 6) s = 6;
   return s < 2 ? 1 : s;
 }

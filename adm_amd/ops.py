@@ -61,7 +61,7 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 # packed-weight cache
 # ------------------------------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "src")
+    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "w2f6", "w2b6", "src")
 
 
 # Contraction precision of the conv / Linear kernels: "f32" (default: exact fp32 MFMA) or "bf16" (BASELINE
@@ -76,6 +76,9 @@ WINO_MIN_M = 8192
 # ... and those with an even height too (not the fused nearest-x2 ones) through the 2-D F(2x2, 3x3) kernel (adm_conv_fwd_wino2d:
 # 2.25x fewer MFMA flops than the direct kernel).  ADM_WINOGRAD2D=0 keeps them on the 1-D kernel.
 WINOGRAD2D = os.environ.get("ADM_WINOGRAD2D", "1") != "0"
+# EXPERIMENTAL (off by default): the same 2-D Winograd convolution with its f32 products carried on the bf16 MFMA through the exact
+# three-term bf16 split of both operands (conv_wino2d_x6.hip: six bf16 MFMAs per product block, f32-level error).
+BF16X6 = os.environ.get("ADM_BF16X6", "0") == "1"
 
 # ADM_DETERMINISTIC=1: bitwise reproducible backward.  The weight / bias gradient kernels normally combine their pixel-range
 # splits with fp32 atomics (order-dependent rounding); with this switch every split stores its partial tile to a workspace
@@ -128,7 +131,19 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
         ent.w2b = _new((16, cip, cop), w)
         call("adm_pack_weight_wino2d", ptr(w), ptr(ent.w2f), ptr(ent.w2b), co, ci, cop, cip)
         _pack_table = None
+    if BF16X6 and ent.w2f6 is None:
+        _split_x6(ent)
     return ent.w2f, ent.w2b
+
+
+def _split_x6(ent: "_Packed"):
+    """[16][3][rows][cols] bf16 images of the 2-D Winograd operands: the exact three-term split a = a0 + a1 + a2."""
+    for src, name in ((ent.w2f, "w2f6"), (ent.w2b, "w2b6")):
+        dst = getattr(ent, name)
+        if dst is None:
+            dst = torch.empty((16, 3) + tuple(src.shape[1:]), device=src.device, dtype=torch.bfloat16)
+            setattr(ent, name, dst)
+        call("adm_split3_bf16", ptr(src), ptr(dst), src.shape[1] * src.shape[2], 16)
 
 
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
@@ -152,6 +167,7 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     ent.fwd16 = ent.bwd16 = None
     ent.wf = ent.wb = None
     ent.w2f = ent.w2b = None
+    ent.w2f6 = ent.w2b6 = None
     ent.src = (co, ci, ks, qkv)
     ent.fwd = _new((cop, ks * ks * cip), w)
     ent.bwd = _new((cip, ks * ks * cop), w)
@@ -225,6 +241,8 @@ def repack_all():
         if b is not None and (qkv or ceil32(co) != co):
             call("adm_permute_vec", ptr(b.detach()), ptr(ent.bias), co, ceil32(co), int(qkv), 0)
         ent.fwd16 = ent.bwd16 = None
+        if ent.w2f6 is not None:
+            _split_x6(ent)
         ent.key = (w.data_ptr(), w._version, _pack_epoch, ks, qkv, None if b is None else (b.data_ptr(), b._version))
 
 
@@ -295,9 +313,15 @@ def _use_wino2d(B, Ho, Wo, ks, up, tile) -> bool:
     return WINOGRAD2D and not up and (Ho & 1) == 0 and _use_wino(B, Ho, Wo, ks, up, tile)
 
 
-def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None, wq2=None):
+def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None, wq2=None, wq6=None):
     """fp32 conv: 2-D Winograd F(2x2,3x3) kernel when `wq2` is given, 1-D F(2,3) when `wq`, else the direct implicit GEMM;
     small-M problems get the deterministic split-K path (workspace + fixed-order reduce)."""
+    if wq2 is not None and wq6 is not None:
+        sk = hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cin_p, n_p)
+        ws = _new((sk * B * Ho * Wo * n_p,), x) if sk > 1 else None
+        call("adm_conv_fwd_wino2d_x6", ptr(x), ptr(wq6), ptr(bias), ptr(res), ptr(y), ptr(ws), 0 if ws is None else ws.numel(), B, Ho,
+             Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
+        return
     if wq2 is not None:
         sk = hip.lib().adm_wino2d_splitk(B, Ho, Wo, cin_p, n_p)
         ws = _new((sk * B * Ho * Wo * n_p,), x) if sk > 1 else None       # small maps: split over the input channels, fixed-order reduce
@@ -348,7 +372,8 @@ class _Conv(torch.autograd.Function):
                 call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
                      Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
-                _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq, wq2)
+                _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq, wq2,
+                          pk.w2f6 if (BF16X6 and wq2 is not None) else None)
         ctx.save_for_backward(x, weight, bias)
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
         return y
@@ -475,7 +500,8 @@ class _Conv(torch.autograd.Function):
                     call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
                          cop, cop, cip, cip, cip, cip, ks, 0, -1)
                 else:
-                    _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1, wq, wq2)
+                    _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1, wq, wq2,
+                              pk.w2b6 if (BF16X6 and wq2 is not None) else None)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
                 call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)

@@ -159,6 +159,60 @@ def test_conv_winograd_2d_forward_backward(ops, monkeypatch, B, cin, cout, H, W)
         assert torch.equal(y.detach(), ops.conv2d.__wrapped__(xd.detach(), dev(w), dev(b), rd.detach())) if hasattr(ops.conv2d, "__wrapped__") else True
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(3, 32, 32, 8, 8), (2, 64, 96, 6, 10), (1, 3, 64, 16, 16), (4, 192, 192, 16, 16), (1, 32, 32, 2, 2),
+                                            (2, 384, 384, 8, 8), (8, 64, 96, 32, 32), (130, 32, 64, 2, 4)])
+def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
+    """EXPERIMENTAL split-bf16 path (conv_wino2d_x6.hip; ADM_BF16X6=1): the 2-D Winograd convolution with every f32 product carried
+    by six bf16 MFMAs on the exact three-term split of both operands.  Same parity bar as the f32 kernels, against F.conv2d."""
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD2D", True)
+    monkeypatch.setattr(ops, "BF16X6", True)
+    x = fill.hash_tensor((B, cin, H, W), f"x6x{cin}{cout}{H}", 1.0)
+    w = fill.hash_tensor((cout, cin, 3, 3), f"x6w{cin}{cout}", 1.0 / math.sqrt(cin * 9))
+    b = fill.hash_tensor((cout,), f"x6b{cin}{cout}", 0.5)
+    r = fill.hash_tensor((B, cout, H, W), f"x6r{cin}{cout}{H}", 1.0)
+    gy = fill.hash_tensor((B, cout, H, W), f"x6g{cin}{cout}{H}", 1.0)
+    xr, wr, br, rr = [t.clone().requires_grad_(True) for t in (x, w, b, r)]
+    y_ref = F.conv2d(xr, wr, br, padding=1) + rr
+    (y_ref * gy).sum().backward()
+    cip, cop = ops.ceil32(cin), ops.ceil32(cout)
+    xd = nhwc(pad_c(x, cip)).requires_grad_(True)
+    wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    rd = nhwc(pad_c(r, cop)).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, rd)
+    assert wd._adm_packed.w2f6 is not None, "the split-bf16 path was not taken"
+    close(nchw(y)[:, :cout], y_ref)
+    (y * nhwc(pad_c(gy, cop))).sum().backward()
+    close(nchw(xd.grad)[:, :cin], xr.grad)
+    close(wd.grad, wr.grad)
+
+
+def test_conv_x6_error_vs_fp64(ops, monkeypatch):
+    """The six-product bf16 emulation must be as accurate as the f32 MFMA kernel it replaces: both are compared with an fp64
+    convolution on zero-mean data AND on all-positive data (no cancellation: the worst case for accumulated rounding)."""
+    B, C, H = 4, 384, 16
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD2D", True)
+    for positive in (False, True):
+        x = fill.hash_tensor((B, C, H, H), "e64x", 1.0)
+        w = fill.hash_tensor((C, C, 3, 3), "e64w", 0.02)
+        if positive:
+            x, w = x.abs(), w.abs()
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        scale = float(F.conv2d(x.double().abs(), w.double().abs(), padding=1).max())
+        err = {}
+        for mode in (False, True):
+            monkeypatch.setattr(ops, "BF16X6", mode)
+            wd = dev(w)
+            y = ops.conv2d(nhwc(x), wd, None)
+            assert (wd._adm_packed.w2f6 is not None) == mode
+            err[mode] = float((nchw(y).double().cpu() - ref).abs().max()) / scale
+        print(f"positive={positive}: max|err| / max sum|ab|: f32 MFMA {err[False]:.3e}, six bf16 products {err[True]:.3e}")
+        assert err[True] <= max(1.5 * err[False], 2e-7), err
+
+
 @pytest.mark.parametrize("B,cin,cout,H,W,up,force", [
     (8, 64, 96, 32, 32, False, False),      # M = 8192: the Winograd weight-gradient kernel is selected BY DEFAULT
     (8, 96, 64, 16, 16, True, False),       # fused nearest x2 (decoder up-conv): grid 32x32, M = 8192, default selection

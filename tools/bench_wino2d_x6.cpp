@@ -1,5 +1,5 @@
 // Diagnostic micro-benchmark for the split-bf16 2-D Winograd kernel (not part of the product).
-// hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DX6_ACC2=0] tools/bench_wino2d_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bx && LD_LIBRARY_PATH=adm_amd /tmp/bx
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/bench_wino2d_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bx && LD_LIBRARY_PATH=adm_amd /tmp/bx
 #include "../adm_amd/csrc/conv_wino2d_x6.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,7 @@ static void run(int B, int H, int Cin, int N, bool check) {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   double fl = 2.0 * B * H * H * (double)N * 9 * Cin;
-  printf("x6 acc2=%d B=%d H=%d Cin=%d N=%d: %.3f ms  %.1f TFLOP/s algorithmic", X6_ACC2, B, H, Cin, N, ms, fl / ms / 1e9);
+  printf("x6 ABL=%d B=%d H=%d Cin=%d N=%d: %.3f ms  %.1f TFLOP/s algorithmic", X6_ABL, B, H, Cin, N, ms, fl / ms / 1e9);
   if (check) {
     adm_conv_fwd_wino2d(x, w, nullptr, nullptr, y2, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
     std::vector<float> a(ny), b(ny);
@@ -36,6 +36,10 @@ static void run(int B, int H, int Cin, int N, bool check) {
   hipFree(x); hipFree(w); hipFree(y); hipFree(y2); hipFree(w6);
 }
 int main() {
+#if X6_ABL
+  run(128, 32, 384, 384, false);
+  return 0;
+#endif
   run(2, 8, 32, 64, true);
   run(128, 32, 384, 384, true);
   run(128, 32, 192, 192, false);

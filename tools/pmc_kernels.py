@@ -44,7 +44,7 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["dur_ns"]):
                   "SQ_ACTIVE_INST_MISC", "SQ_INST_CYCLES_VMEM", "SQ_ACTIVE_INST_VMEM"):
             if c in a:
                 line += f"  {c[3:]}={a[c] / w:.3f}"
-    for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
               "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_BUSY_CU_CYCLES"):
         if c in a:
             line += f"  {c[3:]}={a[c]:.3e}"
