@@ -108,6 +108,9 @@ int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, c
 int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N);
 /* dst[imgs][3][per_img] bf16 <- exact split a = a0 + a1 + a2 of src[imgs][per_img] f32 */
 int adm_split3_bf16(const float* src, void* dst, long per_img, int imgs, hipStream_t stream);
+/* kernel variant of adm_conv_fwd_wino2d: -1 (default) chosen per launch, 1 wave-specialised (producer / consumer waves), 0 symmetric;
+ * returns the old value */
+int adm_wino2d_variant(int ws);
 /* split count (>= 1) adm_conv_fwd_wino2d uses when given a workspace of that many B*H*W*N-float slices (small maps) */
 int adm_wino2d_splitk(int B, int H, int W, int Cin, int N);
 

@@ -29,6 +29,8 @@ static void run(int B, int H, int Cin, int N) {
   hipFree(x); hipFree(w); hipFree(y);
 }
 int main() {
+  if (getenv("W2_WS")) adm_wino2d_variant(atoi(getenv("W2_WS")));
+  printf("variant ws=%d\n", g_w2_ws);
   run(128, 32, 384, 384);
   run(128, 32, 192, 192);
   run(128, 16, 384, 384);
