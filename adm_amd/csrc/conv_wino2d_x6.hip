@@ -15,15 +15,16 @@
 //   * the matrix pipe is no longer the bound, the data path is.  The f32 kernel's stages are as long as a global load takes
 //     (every barrier of a __syncthreads also drains vmcnt), which the 2048-cycle f32 MFMA phase used to cover; a 768-cycle bf16
 //     phase does not.  So the roles are split (512 threads, one workgroup per CU):
-//       - waves 4-7 PRODUCE the A operand: thread = (tile, 16-byte channel quad) loads the whole 4 x 4 input patch of a
-//         16-channel chunk ONCE (16 raw buffer loads, range check = zero padding; the f32 kernel loads 2 rows per pass = 32) into
-//         one of two register sets -- the next chunk's loads are in flight while the four ey sub-stages of the current chunk
-//         are transformed (y combination and B^T along x in f32 exactly as before), split into three bf16 terms (and / sub /
-//         and / sub per element, v_perm packing) and written to LDS (twelve ds_write_b64 per sub-stage);
-//       - waves 0-3 CONSUME: 32 tiles x 32 couts each, six MFMAs per ex plane from C = 0, and the x / y output transforms are
-//         applied to the fresh products of EVERY sub-stage with f32 adds into the output rows held in registers.  The running
-//         sums therefore see one rounded f32 add per 16 channels instead of a truncating matrix add per product: measured
-//         against fp64 the error is at or below the f32 MFMA kernel's (tests/test_hip_ops.py::test_conv_x6_error_vs_fp64).
+//       - waves 4-7 PRODUCE the A operand: thread = (tile, 16-byte channel quad); the loads of a stage (2 rows x 4 pixels, raw
+//         buffer loads, range check = zero padding) are issued FOUR stages ahead into one of four register sets -- these waves hold
+//         no accumulators, so they have the registers for it -- then y-combined and B^T-transformed in f32 exactly as before, split
+//         into three bf16 terms (and / sub / and / sub per element, v_perm packing) and written to LDS (twelve ds_write_b64);
+//       - waves 0-3 CONSUME: 32 tiles x 32 couts each, six MFMAs per ex plane and stage.  Stages are ordered K block (4 chunks) >
+//         ey > chunk: inside a (block, ey) group the accumulators run on (<= 24 matrix adds each, the first from C = 0), at its
+//         end the x / y output transforms are applied and the result is added to the output rows held in registers with f32 adds
+//         -- the long-running sums see rounded f32 adds, not truncating matrix adds: measured against fp64 the error is at or
+//         below the f32 MFMA kernel's (tests/test_hip_ops.py::test_conv_x6_error_vs_fp64).  The four passes over a block also
+//         re-read the input rows 4 stages apart (L2 hits) instead of a whole Cin pass apart.
 //         These waves also issue the weight DMA (their only global accesses: the explicit vmcnt wait before a barrier
 //         never touches the producers' prefetch);
 //       - barriers are s_barrier with LDS-scoped fences (lgkmcnt only): the producers' loads stay in flight across them.
@@ -55,7 +56,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int X6P_T = 64, X6N = 64, X6K = 16;      // tiles x couts x K step
 constexpr int X6_A_STAGE = 4 * 3 * X6P_T * X6K;    // bf16 elements per A sub-stage image (24 KB)
 constexpr int X6_B_STAGE = 4 * 3 * X6N * X6K;
-constexpr int X6_RA = 2, X6_RB = 3;                // ring depths
+constexpr int X6_RA = 2, X6_RB = 4;                // ring depths (weights three stages ahead: a DMA queues behind the producers' loads)
 
 // LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), NOT for its global loads
 __device__ __forceinline__ void x6_barrier() {
@@ -103,14 +104,9 @@ __device__ __forceinline__ void split3_pack(const f32x4 v, u32x2& t0, u32x2& t1,
              __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u)};
 }
 
-// producer: one ey sub-stage of the chunk held in raw[row][pixel] -> the [ex][term] images of A slot `la`
-template <int EY>
-__device__ __forceinline__ void x6_produce(const f32x4 (&raw)[4][4], unsigned short* la) {
+// producer: y-combined rows e[4] (one per pixel of the patch row) -> B^T along x -> three-term split -> the [ex][term] images
+__device__ __forceinline__ void x6_store(const f32x4 (&e)[4], unsigned short* la) {
   if (X6_ABL & 2) return;
-  f32x4 e[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)      // pass ey combines input rows: 0: r0 - r2   1: r1 + r2   2: r2 - r1   3: r1 - r3
-    e[j] = EY == 0 ? sub4(raw[0][j], raw[2][j]) : EY == 1 ? raw[1][j] + raw[2][j] : EY == 2 ? sub4(raw[2][j], raw[1][j]) : sub4(raw[1][j], raw[3][j]);
   const f32x4 v[4] = {sub4(e[0], e[2]), e[1] + e[2], sub4(e[2], e[1]), sub4(e[1], e[3])};
 #pragma unroll
   for (int ex = 0; ex < 4; ++ex) {
@@ -121,6 +117,23 @@ __device__ __forceinline__ void x6_produce(const f32x4 (&raw)[4][4], unsigned sh
     *reinterpret_cast<u32x2*>(la + (ex * 3 + 2) * X6P_T * X6K) = t2;
   }
 }
+
+// Stage order shared by both roles: K blocks of X6_KB chunks outermost, the four ey passes inside a block, chunks innermost
+// (a stage = one (ey, chunk) pair).  Inside a (block, ey) group the MFMA accumulators run on (<= 24 matrix adds each); at its end
+// they are transformed and added to the output rows with f32 adds.
+constexpr int X6_KB = 4;
+struct X6Seq {
+  int k0, len, ey, cc;          // block start (chunk), block length, pass, chunk inside the block
+  __device__ __forceinline__ void init(int chunks) { k0 = 0; len = min(X6_KB, chunks); ey = 0; cc = 0; }
+  __device__ __forceinline__ int chunk() const { return k0 + cc; }
+  __device__ __forceinline__ bool done() const { return len <= 0; }
+  __device__ __forceinline__ void next(int chunks) {
+    if (++cc == len) {
+      cc = 0;
+      if (++ey == 4) { ey = 0; k0 += len; len = min(X6_KB, chunks - k0); }
+    }
+  }
+};
 
 __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem6[];
@@ -146,17 +159,16 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 
   const int c_begin = (p.splitk > 1) ? (int)blockIdx.y * p.chunks_per_split : 0;
   const int chunks = (p.splitk > 1) ? min(p.chunks_per_split, (p.Cin >> 4) - c_begin) : (p.Cin >> 4);     // 16-channel chunks (even)
-  const int S = 4 * chunks;                           // sub-stages: (chunk, ey), ey fastest
+  const int S = 4 * chunks;                           // stages (an even number: Cin is a multiple of 32)
 
   if (producer) {
     // ================================================================ producer waves: A operand
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
     const int ptid = wid * 64 + lane;
     const int pl = ptid >> 2, aq = ptid & 3;          // tile, channel quad
-    unsigned voff[4][4];                              // [row i = 2ty - 1 + i][pixel j = 2xp - 1 + j]
+    unsigned a_base = 0, colmask = 0, rowmask = 0;
     {
       const int t = mt0 + pl;
-      unsigned a_base = 0, colmask = 0, rowmask = 0;
       if (t < p.Mt) {
         const int xp = t % p.Wh;
         const int u = t / p.Wh;
@@ -165,45 +177,69 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
         colmask = (xp > 0 ? 1u : 0u) | 6u | (2 * xp + 2 < p.W ? 8u : 0u);
         rowmask = (ty > 0 ? 1u : 0u) | 6u | (2 * ty + 2 < p.H ? 8u : 0u);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          voff[i][j] = (((rowmask >> i) & 1u) && ((colmask >> j) & 1u))
-                           ? a_base + (unsigned)(((i - 1) * p.W + (j - 1)) * p.ldx * 4) : OOB;
     }
-    auto load_chunk = [&](f32x4 (&raw)[4][4], int c) {
-      const int soff = (c_begin + c) << 6;            // 16 floats = 64 bytes per chunk
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          raw[i][j] = (X6_ABL & 1) ? f32x4{1.f, 2.f, (float)soff, (float)j}
-                                   : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[i][j], soff, 0));
-    };
     // rows are 32 bytes; a 16-lane group of a fragment read covers 16 rows at one 16-byte half, i.e. only half of the banks, unless
     // the halves of rows 8-15 (mod 16) are swapped: physical half = logical half ^ ((row >> 3) & 1), for A and B alike
-    unsigned short* la0 = As + pl * X6K + ((((aq >> 1) ^ (pl >> 3)) & 1) << 3) + (aq & 1) * 4;
-    unsigned short* la1 = la0 + X6_A_STAGE;
-    f32x4 rawA[4][4], rawB[4][4];
-    load_chunk(rawA, 0);
-    // barrier t separates "A(t) written" from compute(t); A(t) goes to slot t & 1 (sub-stage parity = ey parity)
-    for (int c = 0; c < chunks; c += 2) {
-      // the loads of the NEXT chunk are issued here, before this chunk's four sub-stages (sched_barrier: the scheduler would
-      // otherwise sink them to their first use; the last iteration re-reads its own chunk instead of branching)
-      load_chunk(rawB, c + 1);                        // chunks is even: c + 1 always exists
-      __builtin_amdgcn_sched_barrier(0);
-      x6_produce<0>(rawA, la0); x6_barrier();
-      x6_produce<1>(rawA, la1); x6_barrier();
-      x6_produce<2>(rawA, la0); x6_barrier();
-      x6_produce<3>(rawA, la1); x6_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      load_chunk(rawA, min(c + 2, chunks - 1));
-      __builtin_amdgcn_sched_barrier(0);
-      x6_produce<0>(rawB, la0); x6_barrier();
-      x6_produce<1>(rawB, la1); x6_barrier();
-      x6_produce<2>(rawB, la0); x6_barrier();
-      x6_produce<3>(rawB, la1); x6_barrier();
+    unsigned short* la = As + pl * X6K + ((((aq >> 1) ^ (pl >> 3)) & 1) << 3) + (aq & 1) * 4;
+    X6Seq ld; ld.init(chunks);
+    unsigned a_voff[2][4];
+    int voff_ey = -1;
+    auto set_rows = [&]() {     // pass ey combines input rows (iA, iB): 0: +r0 -r2   1: +r1 +r2   2: -r1 +r2   3: +r1 -r3; past the end: nothing
+      const int ey = ld.ey;
+      const int iA = (ey == 0) ? 0 : 1, iB = (ey == 3) ? 3 : 2;
+      const bool live = !ld.done();
+      const bool vA = ((rowmask >> iA) & 1u) && live, vB = ((rowmask >> iB) & 1u) && live;
+      const int offA = (iA - 1) * p.W * p.ldx * 4, offB = (iB - 1) * p.W * p.ldx * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool cv = (colmask >> j) & 1u;
+        a_voff[0][j] = (vA && cv) ? a_base + (unsigned)(offA + (j - 1) * p.ldx * 4) : OOB;
+        a_voff[1][j] = (vB && cv) ? a_base + (unsigned)(offB + (j - 1) * p.ldx * 4) : OOB;
+      }
+      voff_ey = live ? ey : 4;
+    };
+    constexpr int D = 4;                              // stages in flight
+    f32x4 dA[D][4], dB[D][4];
+    int set_ey[D];
+    auto issue = [&](int d) {                         // next stage of the sequence -> register set d
+      if (voff_ey != (ld.done() ? 4 : ld.ey)) set_rows();
+      const int soff = (c_begin + ld.chunk()) << 6;   // 16 floats = 64 bytes per chunk
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (X6_ABL & 1) { dA[d][j] = f32x4{1.f, 2.f, 3.f, (float)soff}; dB[d][j] = f32x4{0.5f, 0.25f, (float)j, 1.f}; continue; }
+        dA[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[0][j], soff, 0));
+        dB[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[1][j], soff, 0));
+      }
+      set_ey[d] = ld.ey;
+      if (!ld.done()) ld.next(chunks);
+    };
+    auto store = [&](int d, int slot) {
+      f32x4 e[4];
+      if (set_ey[d] == 1) {                           // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = dA[d][j] + dB[d][j];
+      } else if (set_ey[d] == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = sub4(dB[d][j], dA[d][j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = sub4(dA[d][j], dB[d][j]);
+      }
+      x6_store(e, la + slot * X6_A_STAGE);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d);
+    __builtin_amdgcn_sched_barrier(0);
+    // barrier t separates "A(t) written" from compute(t); A(t) lives in slot t & 1; set t % D is refilled with stage t + D
+    for (int t = 0; t < S; t += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        store(d, d & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(d);                                     // stages past the end read nothing (all offsets out of range)
+        __builtin_amdgcn_sched_barrier(0);
+        x6_barrier();
+      }
     }
     return;
   }
@@ -216,7 +252,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     p.y = p.ws + (long)blockIdx.y * ((long)p.Mt * 4) * p.N;
     p.ldy = p.N; p.bias = nullptr; p.res = nullptr;
   }
-  // B loader (LDS-DMA): 24 one-KB instructions per sub-stage = (ex, term) image pt x 32-row half; wave w issues q = 6w .. 6w+5.
+  // B loader (LDS-DMA): 24 one-KB instructions per stage = (ex, term) image pt x 32-row half; wave w issues q = 6w .. 6w+5.
   // Lane l of an instruction covers row (q & 1) * 32 + (l >> 1), 16-byte half (l & 1) of the 32-byte row.
   unsigned b_voff[6];
 #pragma unroll
@@ -227,16 +263,21 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     const int half = (lane ^ (row >> 3)) & 1;           // logical half stored at physical half (lane & 1)
     b_voff[i] = (n < p.wrows) ? (unsigned)(((long)pt * p.plane + (long)n * p.Cin + half * 8) * 2) : OOB;
   }
-  auto issue_b = [&](int t) {                         // weights of sub-stage t -> ring slot t % 3
-    const int c = t >> 2, ey = t & 3;
-    const int kb = (ey * 12 * p.plane) * 2 + ((c_begin + c) << 5);   // ey block of twelve [ex][term] images; 32 bytes per chunk
-    unsigned short* lb = Bs + (t % X6_RB) * X6_B_STAGE + (wid * 6) * 512;       // 512 elements = one KB per instruction
-    if (X6_ABL & 4) return;
+  X6Seq lb; lb.init(chunks);
+  int ld_slot = 0;
+  auto issue_b = [&]() {                              // weights of the next stage of the sequence -> next ring slot
+    const int kb = (lb.ey * 12 * p.plane) * 2 + ((c_begin + lb.chunk()) << 5);   // ey block of twelve [ex][term] images; 32 bytes per chunk
+    unsigned short* dst = Bs + ld_slot * X6_B_STAGE + (wid * 6) * 512;           // 512 elements = one KB per instruction
+    if (!(X6_ABL & 4)) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (x6_lds_void*)(lb + i * 512), 16, (int)b_voff[i], kb, 0, 0);
+      for (int i = 0; i < 6; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (x6_lds_void*)(dst + i * 512), 16, (int)b_voff[i], kb, 0, 0);
+    }
+    lb.next(chunks);
+    if (++ld_slot == X6_RB) ld_slot = 0;
   };
 
+  f32x16 acc[4];
   f32x16 Y[2][2];                                     // [output row][output column of the pair]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -248,77 +289,57 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   const int b_foff = (wn * 32 + lr) * X6K + ((lh ^ (lr >> 3)) & 1) * 8;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // one sub-stage: wait for the weights of t (issued two sub-stages ago; only B(t+1)'s six instructions may still be in flight),
-  // barrier (plain s_barrier + explicit counters: a release fence would drain the weight prefetch, vmcnt(0)), issue B(t+2),
-  // 24 MFMAs, output transform with this sub-stage's compile-time signs
-  auto sub_stage = [&](int t, auto ey_c) {
-    constexpr int ey = decltype(ey_c)::value;
-    if (t + 1 < S) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  X6Seq cs; cs.init(chunks);
+  int slot_b = 0;
+  issue_b();
+  issue_b();
+  issue_b();
+  for (int t = 0; t < S; ++t) {
+    // B(t) was issued three stages ago; B(t+1) and B(t+2) (six instructions each) may still be in flight.  Plain s_barrier +
+    // explicit counters: a release fence would drain the weight prefetch (vmcnt(0)).
+    if (t + 2 < S) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (t + 1 < S) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + 2 < S) issue_b(t + 2);
-    const unsigned short* Ab = As + (ey & 1) * X6_A_STAGE + a_foff;
-    const unsigned short* Bb = Bs + (t % X6_RB) * X6_B_STAGE + b_foff;
-    // software pipeline over the four ex planes: the fragments of plane xi+1 are read and its six MFMAs issued before the x output
-    // transform (A^T: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3) consumes plane xi, so the adds run under the next plane's MFMAs and at
-    // most two planes' fragments and products are live
-    bf16x8 fa[2][3], fb[2][3];
-    auto load_frag = [&](int xi, int s) {
+    if (t + 3 < S) issue_b();
+    const unsigned short* Ab = As + (t & 1) * X6_A_STAGE + a_foff;
+    const unsigned short* Bb = Bs + slot_b * X6_B_STAGE + b_foff;
+    if (++slot_b == X6_RB) slot_b = 0;
+    const bool first = cs.cc == 0;                    // first stage of a (block, ey) group: C = 0, no accumulator clearing
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      bf16x8 a[3], b[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         if (X6_ABL & 16) {
-          fa[s][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, (unsigned)t, 0x3f803f80u, (unsigned)xi});
-          fb[s][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f003f00u, (unsigned)k, 0x3f003f00u, (unsigned)lane});
+          a[k] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, (unsigned)t, 0x3f803f80u, (unsigned)xi});
+          b[k] = __builtin_bit_cast(bf16x8, u32x4{0x3f003f00u, (unsigned)k, 0x3f003f00u, (unsigned)lane});
           continue;
         }
-        fa[s][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab + (xi * 3 + k) * X6P_T * X6K));
-        fb[s][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb + (xi * 3 + k) * X6N * X6K));
+        a[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab + (xi * 3 + k) * X6P_T * X6K));
+        b[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb + (xi * 3 + k) * X6N * X6K));
       }
-    };
-    auto six = [&](int s) -> f32x16 {
-      if (X6_ABL & 8) {
-        f32x16 c = zero;
-        c[0] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fa[s][0])[0] ^ __builtin_bit_cast(u32x4, fb[s][2])[1]);
-        c[5] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fa[s][1])[2] ^ __builtin_bit_cast(u32x4, fb[s][1])[3]);
-        c[9] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fa[s][2])[0] ^ __builtin_bit_cast(u32x4, fb[s][0])[0]);
-        return c;
-      }
-      f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][2], zero, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][2], fb[s][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fb[s][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fb[s][0], c, 0, 0, 0);
-      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][0], c, 0, 0, 0);
-    };
-    load_frag(0, 0);
-    load_frag(1, 1);
-    f32x16 z0 = six(0);                       // m0
-    __builtin_amdgcn_sched_barrier(0);
-    load_frag(2, 0);
-    f32x16 m1 = six(1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_frag(3, 1);
-    f32x16 m2 = six(0);
-    z0 += m1;
-    f32x16 z1 = sub16(m1, m2);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 m3 = six(1);
-    z0 += m2;
-    __builtin_amdgcn_sched_barrier(0);
-    z1 = sub16(z1, m3);
-    if (ey <= 2) { Y[0][0] += z0; Y[0][1] += z1; }
-    if (ey == 1) { Y[1][0] += z0; Y[1][1] += z1; }
-    if (ey >= 2) { Y[1][0] = sub16(Y[1][0], z0); Y[1][1] = sub16(Y[1][1], z1); }
-    // pin the output transform inside its sub-stage (left alone, the compiler batches the transforms of four sub-stages at the loop
-    // top and spills for it)
-    asm volatile("" : "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]), "+v"(Y[1][1]));
-  };
-  issue_b(0);
-  issue_b(1);
-  for (int t = 0; t < S; t += 4) {
-    sub_stage(t, std::integral_constant<int, 0>{});
-    sub_stage(t + 1, std::integral_constant<int, 1>{});
-    sub_stage(t + 2, std::integral_constant<int, 2>{});
-    sub_stage(t + 3, std::integral_constant<int, 3>{});
+      if (X6_ABL & 8) continue;
+      // small products first
+      f32x16 c;
+      if (first) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], zero, 0, 0, 0);       // (wave-uniform branch)
+      else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[xi], 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    }
+    const int ey = cs.ey;
+    const bool last = cs.cc + 1 == cs.len;
+    cs.next(chunks);
+    if (last) {
+      // end of a (block, ey) group: A^T along x (z0 = m0 + m1 + m2, z1 = m1 - m2 - m3), then A^T along y into the output rows
+      // (row 0 += Z(ey = 0, 1, 2); row 1 += Z(1) - Z(2) - Z(3)) with f32 adds
+      const f32x16 z0 = acc[0] + acc[1] + acc[2], z1 = sub16(sub16(acc[1], acc[2]), acc[3]);
+      if (ey <= 2) { Y[0][0] += z0; Y[0][1] += z1; }
+      if (ey == 1) { Y[1][0] += z0; Y[1][1] += z1; }
+      if (ey >= 2) { Y[1][0] = sub16(Y[1][0], z0); Y[1][1] = sub16(Y[1][1], z1); }
+    }
   }
 
   // ---- epilogue.  C/D layout col = lane&31 (cout), row = (r&3) + 8 (r>>2) + 4 (lane>>5) (tile)

@@ -299,8 +299,8 @@ __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __res
 // Thread map as above restricted to the chunk: Cc4 = Cc/4 quads, R = blockDim / Cc4 rows in flight, each thread owns
 // rows ry, ry + R, ... (<= MAXR of them).  Reductions keep the fixed summation order of the multi-launch path
 // (deterministic), with the same fp64 group combine.
-template <int MAXR>
-__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <int MAXR, int THREADS>
+__global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 3)) void gn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
                                                            long ss_bstride, float* __restrict__ y,
                                                            float* __restrict__ stats, int HW, int C, int G, int Cc,
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
   extern __shared__ float sm[];                    // [R][Cc][2] partials | [Gc][2] mean, rstd
   const int Cc4 = Cc >> 2, R = blockDim.x / Cc4, C4 = C >> 2;
   const int cq = threadIdx.x % Cc4, ry = threadIdx.x / Cc4;
-  const int b = blockIdx.x, c0 = blockIdx.y * Cc;
+  const int b = blockIdx.y, c0 = blockIdx.x * Cc;        // slabs of one image are adjacent in launch order: they share cache lines
   const int cpg = C / G, Gc = Cc / cpg, g0 = c0 / cpg;
   const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C + c0);
   f32x4 v[MAXR];
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
     const int hw = ry + i * R;
-    v[i] = f32x4{0, 0, 0, 0};
-    if (hw < HW) v[i] = xb[(long)hw * C4 + cq];
+    const f32x4 t = xb[(long)min(hw, HW - 1) * C4 + cq];          // unconditional (clamped) load: no branch per row
+    v[i] = hw < HW ? t : f32x4{0, 0, 0, 0};
   }
   // the slab is in registers: a true two-pass per thread (own mean first, then squared deviations), merged in fp64
   int nrow = 0;
@@ -333,29 +333,42 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) { p1[2 * k] = tm[k]; p1[2 * k + 1] = s2[k]; }
   __syncthreads();
-  float* gs = sm + R * Cc * 2;
+  // exact merge of the per-thread (n, mean, M2) triples in fp64, fixed order: per channel over the R row lanes (one thread per
+  // channel), then per group over its channels -- sum_r n_r mean_rc first, the squared deviations against the GROUP mean second
+  float* gs = sm + R * Cc * 2;                     // [Gc][2] mean, rstd
+  double* chd = reinterpret_cast<double*>(gs + ((Gc * 2 + 1) & ~1));      // [Cc] per-channel fp64 partial
+  const int Rl = min(R, HW);
+  for (int cl = threadIdx.x; cl < Cc; cl += blockDim.x) {
+    double a = 0.0;
+    for (int r = 0; r < Rl; ++r) a += (double)sm[(r * Cc + cl) * 2] * (double)((HW - r + R - 1) / R);
+    chd[cl] = a;
+  }
+  __syncthreads();
   if ((int)threadIdx.x < Gc) {
     const int g = threadIdx.x;
-    double N = 0.0, sum = 0.0;
-    for (int r = 0; r < R && r < HW; ++r) {
-      const double n = (double)((HW - r + R - 1) / R);
-      double a = 0.0;
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += (double)sm[(r * Cc + c) * 2];
-      sum += a * n; N += n * cpg;
-    }
-    const double mean = sum / N;
+    double sum = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) sum += chd[c];
+    gs[2 * g] = (float)(sum / ((double)HW * cpg));
+  }
+  __syncthreads();
+  for (int cl = threadIdx.x; cl < Cc; cl += blockDim.x) {
+    const double mean = (double)gs[2 * (cl / cpg)];       // the group mean rounded to f32, as it is applied
     double m2 = 0.0;
-    for (int r = 0; r < R && r < HW; ++r) {
-      const double n = (double)((HW - r + R - 1) / R);
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        const double d = (double)sm[(r * Cc + c) * 2] - mean;
-        m2 += (double)sm[(r * Cc + c) * 2 + 1] + n * d * d;
-      }
+    for (int r = 0; r < Rl; ++r) {
+      const double d = (double)sm[(r * Cc + cl) * 2] - mean;
+      m2 += (double)sm[(r * Cc + cl) * 2 + 1] + (double)((HW - r + R - 1) / R) * d * d;
     }
-    double var = m2 / N;
+    chd[cl] = m2;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < Gc) {
+    const int g = threadIdx.x;
+    double m2 = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) m2 += chd[c];
+    double var = m2 / ((double)HW * cpg);
     if (var < 0.0) var = 0.0;
-    const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
-    gs[2 * g] = m; gs[2 * g + 1] = rs;
+    const float m = gs[2 * g], rs = (float)(1.0 / sqrt(var + (double)eps));
+    gs[2 * g + 1] = rs;
     stats[((long)b * G + g0 + g) * 2] = m;
     stats[((long)b * G + g0 + g) * 2 + 1] = rs;
   }
@@ -384,11 +397,14 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
     }
     if (drop_p > 0.f) u *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + (c0 >> 2) + cq, drop_p, inv_keep);
     yb[(long)hw * C4 + cq] = u;
+    __builtin_amdgcn_sched_barrier(0);            // one row at a time: interleaving the rows' hashes / exponentials costs registers
   }
 }
 
-template <int MAXR>
-__global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// (second launch bound = waves per SIMD: left alone the compiler hoists the dropout hashes and SiLU derivatives of all rows and
+// takes 186-256 registers, i.e. one or two waves per SIMD for a bandwidth-bound kernel)
+template <int MAXR, int THREADS>
+__global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 2)) void gn_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
                                                            long ss_bstride, const float* __restrict__ addend,
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
   extern __shared__ float sm[];                    // [R][Cc][2] partials | [Cc][2] gamma' R1, gamma' R2 | [Gc][2] m1, m2
   const int Cc4 = Cc >> 2, R = blockDim.x / Cc4, C4 = C >> 2;
   const int cq = threadIdx.x % Cc4, ry = threadIdx.x / Cc4;
-  const int b = blockIdx.x, c0 = blockIdx.y * Cc;
+  const int b = blockIdx.y, c0 = blockIdx.x * Cc;        // slabs of one image are adjacent in launch order: they share cache lines
   const int cpg = C / G, Gc = Cc / cpg, g0 = c0 / cpg;
   f32x4 ca, cb, cm, cr;
 #pragma unroll
@@ -420,8 +436,10 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
     const int hw = ry + i * R;
-    xh[i] = f32x4{0, 0, 0, 0}; d[i] = f32x4{0, 0, 0, 0};
-    if (hw < HW) { xh[i] = xb[(long)hw * C4 + cq]; d[i] = gb[(long)hw * C4 + cq]; }
+    const long off = (long)min(hw, HW - 1) * C4 + cq;              // unconditional (clamped) loads: no branch per row
+    const f32x4 tx = xb[off], td = gb[off];
+    xh[i] = hw < HW ? tx : f32x4{0, 0, 0, 0};
+    d[i] = hw < HW ? td : f32x4{0, 0, 0, 0};
   }
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
@@ -439,6 +457,7 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
     d[i] = dd;
     r1 += dd;
     r2 += dd * xh[i];
+    __builtin_amdgcn_sched_barrier(0);            // one row at a time (see the forward kernel)
   }
   float* p1 = sm + (ry * Cc + cq * 4) * 2;
 #pragma unroll
@@ -490,17 +509,27 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
   }
 }
 
-// chunk width for the fused path: whole groups, quads not straddling groups, <= 128 channels, <= 14 rows per thread
-inline int gn_fused_chunk(int HW, int C, int G) {
+// Plan of the one-launch path: slab width Cc (whole groups, whole channel quads, <= 128 channels), workgroup size and rows per
+// thread (<= 14).
+struct GnPlan { int Cc, threads, rows; };
+inline GnPlan gn_fused_plan(int HW, int C, int G, bool backward) {
   const int cpg = C / G;
-  if (HW > 256 || (cpg & 3)) return 0;
-  int best = 0;
+  GnPlan best{0, 0, 0};
+  // Above 16x16 the streaming multi-pass kernels win: measured at 32x32 (tools/bench_gn.py, bs=128) the register-resident
+  // forward is 8-60 % SLOWER (1024-thread workgroups, one per CU: loads, reduction and stores of a CU no longer overlap; and the
+  // second read of a 100 MB map is served by the 256 MB Infinity Cache anyway), the backward equal within 1 %.
+  if (HW > 256) return best;
+  const int threads = 256;
+  (void)backward;
   for (int k = 1; k <= G; ++k) {
     if (G % k) continue;
     const int Cc = cpg * k;
+    if (Cc & 3) continue;                    // whole float4 quads (a quad may straddle two groups: the kernels map channels, not quads)
     if (Cc > 128) break;
-    const int R = 256 / (Cc / 4);
-    if (R >= 1 && (HW + R - 1) / R <= 14) best = Cc;
+    const int R = threads / (Cc / 4);
+    if (R < 1) continue;
+    const int rows = (HW + R - 1) / R;
+    if (rows <= 14) best = GnPlan{Cc, (Cc / 4) * R, rows};      // widest slab that fits: longest contiguous row segments
   }
   return best;
 }
@@ -511,6 +540,9 @@ inline bool gn_shape_ok(int B, int HW, int C, int G) {
 inline int gn_threads(int C) { return (C / 4) * gn_rows_par(C); }
 
 }  // namespace
+
+int g_gn_fused = 1;       // 0: always the multi-pass kernels (diagnostic; tools only)
+extern "C" int adm_gn_fused(int on) { const int old = g_gn_fused; if (on == 0 || on == 1) g_gn_fused = on; return old; }
 
 extern "C" int adm_gn_splits(int HW, int C) {
   (void)C;
@@ -552,25 +584,22 @@ extern "C" int adm_gn_fwd(const float* x, float* stats, double* ws, const float*
                           uint64_t seed, hipStream_t stream) {
   if (!x || !stats || !ws || !gamma || !beta || !y || !gn_shape_ok(B, HW, C, G) || drop_p < 0.f || drop_p >= 1.f)
     return ADM_EINVAL;
-  // forward: only up to 8x8 -- at 16x16 the 48-channel chunks (192-byte row segments) cost more than the saved pass
-  const int Cc = HW <= 64 ? gn_fused_chunk(HW, C, G) : 0;
-  if (Cc == 0) {
+  const GnPlan pl = g_gn_fused ? gn_fused_plan(HW, C, G, false) : GnPlan{0, 0, 0};
+  if (pl.Cc == 0) {
     int rc = adm_gn_stats(x, stats, ws, B, HW, C, G, eps, stream);
     if (rc != ADM_OK) return rc;
     return adm_gn_apply(x, stats, gamma, beta, ss, ss_bstride, y, B, HW, C, G, silu, drop_p, seed, stream);
   }
-  const int Cc4 = Cc / 4, R = 256 / Cc4, rows = (HW + R - 1) / R, Gc = Cc / (C / G);
-  const size_t smem = ((size_t)R * Cc * 2 + (size_t)Gc * 2) * sizeof(float);
-  const dim3 grid(B, C / Cc), block(Cc4 * R);
-  if (rows <= 2)
-    hipLaunchKernelGGL(gn_fused_fwd_kernel<2>, grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, HW, C, G,
-                       Cc, eps, silu, drop_p, seed);
-  else if (rows <= 8)
-    hipLaunchKernelGGL(gn_fused_fwd_kernel<8>, grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, HW, C, G,
-                       Cc, eps, silu, drop_p, seed);
-  else
-    hipLaunchKernelGGL(gn_fused_fwd_kernel<14>, grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, HW, C, G,
-                       Cc, eps, silu, drop_p, seed);
+  const int Cc = pl.Cc, R = pl.threads / (Cc / 4), Gc = Cc / (C / G);
+  const size_t smem = ((size_t)R * Cc * 2 + (size_t)((Gc * 2 + 1) & ~1)) * sizeof(float) + (size_t)Cc * sizeof(double);
+  const dim3 grid(C / Cc, B), block(pl.threads);
+#define GN_FWD(MAXR, THREADS)                                                                                                 \
+  hipLaunchKernelGGL((gn_fused_fwd_kernel<MAXR, THREADS>), grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, \
+                     HW, C, G, Cc, eps, silu, drop_p, seed)
+  if (pl.rows <= 2) GN_FWD(2, 256);
+  else if (pl.rows <= 8) GN_FWD(8, 256);
+  else GN_FWD(14, 256);
+#undef GN_FWD
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -594,20 +623,18 @@ extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stat
   float* part = red;
   float* tot = part + (long)B * S * C * 2;
   float* gm = tot + (long)B * C * 2;
-  const int Cc = gn_fused_chunk(HW, C, G);
-  if (Cc) {          // small feature map: one launch (+ the parameter-gradient reduction over the batch)
-    const int Cc4 = Cc / 4, Rf = 256 / Cc4, rws = (HW + Rf - 1) / Rf, Gc = Cc / (C / G);
+  const GnPlan pl = g_gn_fused ? gn_fused_plan(HW, C, G, true) : GnPlan{0, 0, 0};
+  if (pl.Cc) {       // one launch (+ the parameter-gradient reduction over the batch)
+    const int Cc = pl.Cc, Rf = pl.threads / (Cc / 4), Gc = Cc / (C / G);
     const size_t smf = ((size_t)Rf * Cc * 2 + (size_t)Cc * 2 + (size_t)Gc * 2) * sizeof(float);
-    const dim3 grid(B, C / Cc), block(Cc4 * Rf);
-    if (rws <= 2)
-      hipLaunchKernelGGL(gn_fused_bwd_kernel<2>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx, tot,
-                         dss, HW, C, G, Cc, silu, drop_p, seed);
-    else if (rws <= 8)
-      hipLaunchKernelGGL(gn_fused_bwd_kernel<8>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx, tot,
-                         dss, HW, C, G, Cc, silu, drop_p, seed);
-    else
-      hipLaunchKernelGGL(gn_fused_bwd_kernel<14>, grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx,
-                         tot, dss, HW, C, G, Cc, silu, drop_p, seed);
+    const dim3 grid(C / Cc, B), block(pl.threads);
+#define GN_BWD(MAXR, THREADS)                                                                                                   \
+  hipLaunchKernelGGL((gn_fused_bwd_kernel<MAXR, THREADS>), grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, \
+                     addend, dx, tot, dss, HW, C, G, Cc, silu, drop_p, seed)
+    if (pl.rows <= 2) GN_BWD(2, 256);
+    else if (pl.rows <= 8) GN_BWD(8, 256);
+    else GN_BWD(14, 256);
+#undef GN_BWD
     if (dgamma)
       hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(adm_cdiv(C, 32)), dim3(256), 0, stream, tot, ss, ss_bstride, dgamma,
                          dbeta, B, C);

@@ -51,6 +51,7 @@ _SIGS = {
     "adm_permute_vec": [P, P, I, I, I, I, P],
     "adm_colsum": [P, P, I, I, I, I, P],
     "adm_gn_splits": [I, I],
+    "adm_gn_fused": [I],
     "adm_gn_stats": [P, P, P, I, I, I, I, F, P],
     "adm_gn_apply": [P, P, P, P, P, L, P, I, I, I, I, I, F, U, P],
     "adm_gn_fwd": [P, P, P, P, P, P, L, P, I, I, I, I, F, I, F, U, P],
@@ -142,7 +143,7 @@ def ptr(t) -> c_void_p:
 
 
 NO_STREAM = ("adm_version", "adm_conv_splitk", "adm_gn_splits", "adm_aug_workspace_floats", "adm_conv_wgrad_plan",
-             "adm_sumsq_blocks", "adm_lnc_blocks", "adm_bn_blocks", "adm_linattn_ws_floats", "adm_wino2d_splitk", "adm_wino2d_x6_splitk", "adm_wino2d_variant")      # host-side queries: no stream argument, called as lib().name(...)
+             "adm_sumsq_blocks", "adm_lnc_blocks", "adm_bn_blocks", "adm_linattn_ws_floats", "adm_wino2d_splitk", "adm_wino2d_x6_splitk", "adm_wino2d_variant", "adm_gn_fused")      # host-side queries: no stream argument, called as lib().name(...)
 
 
 def call(name: str, *args):

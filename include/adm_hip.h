@@ -174,6 +174,8 @@ int adm_colsum(const float* a, float* out, int M, int N, int ld, int accumulate,
 
 /* stats[b][g] = {mean, rstd} of x[b, :, g*cpg:(g+1)*cpg]; ws: scratch of B*splits*G*2 doubles
  * (splits = adm_gn_splits(HW, C)).  F.group_norm's moments (uncond_unet.py:128). */
+/* 1 (default): one-launch register-resident GroupNorm where a plan exists; 0: always the multi-pass kernels.  Returns the old value. */
+int adm_gn_fused(int on);
 int adm_gn_splits(int HW, int C);
 int adm_gn_stats(const float* x, float* stats, double* ws, int B, int HW, int C, int G, float eps, hipStream_t stream);
 /* y = act( (xhat*gamma + beta) * (1 + scale[b,c]) + shift[b,c] ) * dropmask
