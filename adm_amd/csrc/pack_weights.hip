@@ -103,12 +103,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 }
 
 // One launch for ALL layers of a model.  table[e] = {src, dst_fwd, dst_bwd, Co, Ci, taps, Co_pad, Ci_pad, qkv, tile_begin,
-// dst_wino_fwd, dst_wino_bwd} (int64 each; tile_begin = exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) over the rows, in
+// dst_wino_fwd, dst_wino_bwd, dst_wino2d_fwd, dst_wino2d_bwd, dst_x6_fwd, dst_x6_bwd} (int64 each; tile_begin = exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) over the rows, in
 // row order; the two Winograd destinations are 0 for layers that do not use conv_wino.hip).  One workgroup per 32
 // (out-channel) x 32 (in-channel) tile of one layer: the tile's taps-interleaved source runs (32*taps contiguous floats per
 // out-channel) go through LDS once and leave as 128-byte row segments of every operand layout, so reads and writes are
 // coalesced (the previous element-per-thread gather ran at 0.7 TB/s and cost 3.8 ms per optimiser step).
-constexpr int PT_COLS = 14;
+constexpr int PT_COLS = 16;
 __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict__ table, int n_entries) {
   __shared__ float tile[32][32 * 9 + 1];
   // layer of this tile: last row whose tile_begin <= blockIdx.x
@@ -164,15 +164,19 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
     }
   }
   // 2-D Winograd F(2x2, 3x3) operands (conv_wino2d.hip): U = G g G^T, plane ey * 4 + ex
+  // ... and their exact three-term bf16 splits [16][3][rows][cols] for conv_wino2d_x6.hip (columns 14, 15; 0 when unused)
   float* __restrict__ wf2 = reinterpret_cast<float*>(t[12]);
   float* __restrict__ wb2 = reinterpret_cast<float*>(t[13]);
-  if (wf2 || wb2) {
+  unsigned short* __restrict__ wf6 = reinterpret_cast<unsigned short*>(t[14]);
+  unsigned short* __restrict__ wb6 = reinterpret_cast<unsigned short*>(t[15]);
+  if (wf2 || wb2 || wf6 || wb6) {
     const long plane2 = (long)Co_pad * Ci_pad;
     for (int e = threadIdx.x; e < 32 * 32; e += 256) {
       // forward operand: ci fastest; data-gradient operand: co fastest -> two index maps over the same 32 x 32 tile
       for (int which = 0; which < 2; ++which) {
         float* __restrict__ dst = which ? wb2 : wf2;
-        if (!dst) continue;
+        unsigned short* __restrict__ dst6 = which ? wb6 : wf6;
+        if (!dst && !dst6) continue;
         const int fast = e & 31, slow = e >> 5;
         const int co_l = which ? fast : slow, ci_l = which ? slow : fast;
         const float* g = &tile[co_l][ci_l * 9];
@@ -187,10 +191,21 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
 #pragma unroll
         for (int ex = 0; ex < 4; ++ex) {
           const float c0 = tr[0][ex], c1 = tr[1][ex], c2 = tr[2][ex];
-          dst[(long)(0 * 4 + ex) * plane2 + o] = c0;
-          dst[(long)(1 * 4 + ex) * plane2 + o] = (c0 + c1 + c2) * 0.5f;
-          dst[(long)(2 * 4 + ex) * plane2 + o] = (c0 - c1 + c2) * 0.5f;
-          dst[(long)(3 * 4 + ex) * plane2 + o] = c2;
+          const float u[4] = {c0, (c0 + c1 + c2) * 0.5f, (c0 - c1 + c2) * 0.5f, c2};
+#pragma unroll
+          for (int ey = 0; ey < 4; ++ey) {
+            if (dst) dst[(long)(ey * 4 + ex) * plane2 + o] = u[ey];
+            if (dst6) {                            // a = a0 + a1 + a2 exactly (truncation splits, as adm_split3_bf16)
+              const unsigned b0 = __float_as_uint(u[ey]);
+              const float r1 = u[ey] - __uint_as_float(b0 & 0xFFFF0000u);
+              const unsigned b1 = __float_as_uint(r1);
+              const float r2 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
+              unsigned short* d6 = dst6 + (long)(ey * 4 + ex) * 3 * plane2 + o;
+              d6[0] = (unsigned short)(b0 >> 16);
+              d6[plane2] = (unsigned short)(b1 >> 16);
+              d6[2 * plane2] = (unsigned short)(__float_as_uint(r2) >> 16);
+            }
+          }
         }
       }
     }

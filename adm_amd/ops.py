@@ -76,9 +76,10 @@ WINO_MIN_M = 8192
 # ... and those with an even height too (not the fused nearest-x2 ones) through the 2-D F(2x2, 3x3) kernel (adm_conv_fwd_wino2d:
 # 2.25x fewer MFMA flops than the direct kernel).  ADM_WINOGRAD2D=0 keeps them on the 1-D kernel.
 WINOGRAD2D = os.environ.get("ADM_WINOGRAD2D", "1") != "0"
-# EXPERIMENTAL (off by default): the same 2-D Winograd convolution with its f32 products carried on the bf16 MFMA through the exact
-# three-term bf16 split of both operands (conv_wino2d_x6.hip: six bf16 MFMAs per product block, f32-level error).
-BF16X6 = os.environ.get("ADM_BF16X6", "0") == "1"
+# ... with their f32 products carried on the bf16 MFMA through the EXACT three-term bf16 split of both operands (conv_wino2d_x6.hip:
+# six bf16 MFMAs per product block, f32 accumulation; error against fp64 at or below the f32 MFMA kernel's, see
+# tests/test_hip_ops.py::test_conv_x6_error_vs_fp64).  ADM_BF16X6=0 keeps the f32-MFMA kernels of conv_wino2d.hip.
+BF16X6 = os.environ.get("ADM_BF16X6", "1") != "0"
 
 # ADM_DETERMINISTIC=1: bitwise reproducible backward.  The weight / bias gradient kernels normally combine their pixel-range
 # splits with fp32 atomics (order-dependent rounding); with this switch every split stores its partial tile to a workspace
@@ -133,6 +134,7 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
         _pack_table = None
     if BF16X6 and ent.w2f6 is None:
         _split_x6(ent)
+        _pack_table = None           # the one-launch repack table must learn the new destinations
     return ent.w2f, ent.w2b
 
 
@@ -220,7 +222,8 @@ def repack_all():
             cop, cip = ceil32(co), ceil32(ci)
             rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv), tiles,
                          0 if ent.wf is None else ent.wf.data_ptr(), 0 if ent.wb is None else ent.wb.data_ptr(),
-                         0 if ent.w2f is None else ent.w2f.data_ptr(), 0 if ent.w2b is None else ent.w2b.data_ptr()])
+                         0 if ent.w2f is None else ent.w2f.data_ptr(), 0 if ent.w2b is None else ent.w2b.data_ptr(),
+                         0 if ent.w2f6 is None else ent.w2f6.data_ptr(), 0 if ent.w2b6 is None else ent.w2b6.data_ptr()])
             tiles += (cop // 32) * (cip // 32)         # column 9 = exclusive prefix sum of 32x32 tiles
             ents.append((wref, bref, ks, qkv, ent))
         if not rows:
@@ -241,8 +244,6 @@ def repack_all():
         if b is not None and (qkv or ceil32(co) != co):
             call("adm_permute_vec", ptr(b.detach()), ptr(ent.bias), co, ceil32(co), int(qkv), 0)
         ent.fwd16 = ent.bwd16 = None
-        if ent.w2f6 is not None:
-            _split_x6(ent)
         ent.key = (w.data_ptr(), w._version, _pack_epoch, ks, qkv, None if b is None else (b.data_ptr(), b._version))
 
 
@@ -365,7 +366,7 @@ class _Conv(torch.autograd.Function):
         wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv
         wq2 = _wino2_operands(weight, pk)[0] if (wino and _use_wino2d(B, Ho, Wo, ks, up, tile)) else None
         wq = _wino_operands(weight, pk)[0] if (wino and wq2 is None) else None
-        kind = "wino2" if wq2 is not None else "wino" if wq is not None else "igemm"
+        kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "igemm"
         with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                    f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
             if use_bf16:
@@ -493,7 +494,7 @@ class _Conv(torch.autograd.Function):
             wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, False, -1) and not qkv
             wq2 = _wino2_operands(weight, pk)[1] if (wino and _use_wino2d(B, Ho, Wo, ks, False, -1)) else None
             wq = _wino_operands(weight, pk)[1] if (wino and wq2 is None) else None
-            kind = "wino2" if wq2 is not None else "wino" if wq is not None else "igemm"
+            kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "igemm"
             with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                        f"dgrad{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
                 if use_bf16:

@@ -129,6 +129,7 @@ def test_conv_winograd_2d_forward_backward(ops, monkeypatch, request, B, cin, co
     monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     monkeypatch.setattr(ops, "WINOGRAD", True)
     monkeypatch.setattr(ops, "WINOGRAD2D", True)
+    monkeypatch.setattr(ops, "BF16X6", False)                 # the f32-MFMA kernels of conv_wino2d.hip (ADM_BF16X6=0)
     from adm_amd import hip as _hip
     old_variant = _hip.lib().adm_wino2d_variant(variant)      # 0: symmetric kernel, 1: wave-specialised kernel
     request.addfinalizer(lambda: _hip.lib().adm_wino2d_variant(old_variant))
@@ -165,8 +166,8 @@ def test_conv_winograd_2d_forward_backward(ops, monkeypatch, request, B, cin, co
 @pytest.mark.parametrize("B,cin,cout,H,W", [(3, 32, 32, 8, 8), (2, 64, 96, 6, 10), (1, 3, 64, 16, 16), (4, 192, 192, 16, 16), (1, 32, 32, 2, 2),
                                             (2, 384, 384, 8, 8), (8, 64, 96, 32, 32), (130, 32, 64, 2, 4)])
 def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
-    """EXPERIMENTAL split-bf16 path (conv_wino2d_x6.hip; ADM_BF16X6=1): the 2-D Winograd convolution with every f32 product carried
-    by six bf16 MFMAs on the exact three-term split of both operands.  Same parity bar as the f32 kernels, against F.conv2d."""
+    """The default 3x3 path (conv_wino2d_x6.hip): the 2-D Winograd convolution with every f32 product carried by six bf16 MFMAs on
+    the exact three-term split of both operands.  Same parity bar as the f32-MFMA kernels, against F.conv2d."""
     monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     monkeypatch.setattr(ops, "WINOGRAD", True)
     monkeypatch.setattr(ops, "WINOGRAD2D", True)
@@ -183,12 +184,39 @@ def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
     xd = nhwc(pad_c(x, cip)).requires_grad_(True)
     wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     rd = nhwc(pad_c(r, cop)).requires_grad_(True)
+    monkeypatch.setattr(ops, "PROFILE", [])
     y = ops.conv2d(xd, wd, bd, rd)
     assert wd._adm_packed.w2f6 is not None, "the split-bf16 path was not taken"
     close(nchw(y)[:, :cout], y_ref)
     (y * nhwc(pad_c(gy, cop))).sum().backward()
+    assert [rec[0] for rec in ops.PROFILE].count("wino2x6") == 2        # forward + data gradient
     close(nchw(xd.grad)[:, :cin], xr.grad)
     close(wd.grad, wr.grad)
+
+
+def test_conv_x6_weights_follow_repack_all(ops, monkeypatch):
+    """The fused optimiser rewrites parameters through raw pointers and refreshes every packed operand with one launch
+    (ops.repack_all): the split-bf16 images must follow, bit for bit as adm_split3_bf16 would produce them."""
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD2D", True)
+    monkeypatch.setattr(ops, "BF16X6", True)
+    x = fill.hash_tensor((2, 64, 8, 8), "rpx", 1.0)
+    w = torch.nn.Parameter(dev(fill.hash_tensor((96, 64, 3, 3), "rpw", 0.05)))
+    y0 = ops.conv2d(nhwc(x), w, None)
+    pk = w._adm_packed
+    assert pk.w2f6 is not None
+    with torch.no_grad():
+        w.data.mul_(1.5).add_(0.01)              # in place, as the optimiser kernel does (same storage)
+    ops.repack_all()
+    assert w._adm_packed is pk
+    y1 = ops.conv2d(nhwc(x), w, None)
+    close(nchw(y1)[:, :96], F.conv2d(x, w.detach().cpu(), padding=1))
+    assert not torch.equal(y0, y1)
+    want = torch.empty_like(pk.w2f6)
+    from adm_amd import hip as _hip
+    _hip.call("adm_split3_bf16", pk.w2f.data_ptr(), want.data_ptr(), pk.w2f.shape[1] * pk.w2f.shape[2], 16)
+    assert torch.equal(want.view(torch.int16), pk.w2f6.view(torch.int16))
 
 
 def test_conv_x6_error_vs_fp64(ops, monkeypatch):

@@ -115,27 +115,32 @@ def test_sampler_step_fixed_point_and_range(ops):
     assert float(z.min()) >= 0.0 and float(z.max()) <= 1.0
 
 
-@pytest.mark.parametrize("two_d", [True, False])
+@pytest.mark.parametrize("mode", ["x6", "2d", "1d"])
 @pytest.mark.parametrize("B,H,cin,cout", [(128, 32, 192, 192), (128, 16, 768, 384), (128, 8, 384, 384)])
-def test_winograd_and_direct_kernels_agree_full_size(ops, monkeypatch, B, H, cin, cout, two_d):
-    """At BASELINE's sizes the 3x3 convs run through the Winograd kernels -- 2-D F(2x2,3x3) / F(3x3,2x2) by default (incl. the
-    split-K small-map launches), 1-D F(2,3) / F(3,2) with ADM_WINOGRAD2D=0; forward, data gradient, weight gradient and bias
-    gradient must agree with the direct implicit-GEMM kernels to fp32 rounding (different summation orders, same arithmetic)."""
+def test_winograd_and_direct_kernels_agree_full_size(ops, monkeypatch, B, H, cin, cout, mode):
+    """At BASELINE's sizes the 3x3 convs run through the Winograd kernels -- by default 2-D F(2x2,3x3) with the f32 products on the
+    bf16 MFMA by exact three-term splitting ("x6": conv_wino2d_x6.hip) and the f32-MFMA F(3x3,2x2) weight gradient, incl. the
+    split-K small-map launches; ADM_BF16X6=0 -> the f32-MFMA 2-D kernels ("2d"); ADM_WINOGRAD2D=0 -> 1-D F(2,3) / F(3,2) ("1d").
+    Forward, data gradient, weight gradient and bias gradient must agree with the direct implicit-GEMM kernels to fp32 rounding
+    (different summation orders, same arithmetic)."""
     x = rnd((B, H, H, cin), 11)
     w0 = rnd((cout, cin, 3, 3), 12, 1 / math.sqrt(cin * 9))
     b0 = rnd((cout,), 13)
     gy = rnd((B, H, H, cout), 14)
     out = {}
+    two_d = mode != "1d"
     monkeypatch.setattr(ops, "WINOGRAD2D", two_d)
-    for mode in (True, False):
-        monkeypatch.setattr(ops, "WINOGRAD", mode)
+    monkeypatch.setattr(ops, "BF16X6", mode == "x6")
+    for wino in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", wino)
         xd = x.clone().requires_grad_(True)
         w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
         y = ops.conv2d(xd, w, b)
         pk = w._adm_packed
-        assert (pk.w2f is not None) == (mode and two_d) and (pk.wf is not None) == (mode and not two_d)
+        assert (pk.w2f is not None) == (wino and two_d) and (pk.wf is not None) == (wino and not two_d)
+        assert (pk.w2f6 is not None) == (wino and mode == "x6")
         (y * gy).sum().backward()
-        out[mode] = (y.detach(), xd.grad, w.grad, b.grad)
+        out[wino] = (y.detach(), xd.grad, w.grad, b.grad)
     for got, want, name in zip(out[True], out[False], ("y", "dx", "dw", "db")):
         err = float((got - want).abs().max() / want.abs().max())
         assert err <= (4e-5 if two_d else 2e-5), (name, err)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 outputs under gpurun_out/ (kernel stats + three --pmc passes) into the committed
-summaries under profiles/.  Usage: python tools/summarize_profiles.py <stats_dir> <pmc_prefix> <tag> <steps>"""
+summaries under profiles/.  Usage: python tools/summarize_profiles.py <stats_dir> <pmc_prefix> <tag> <steps> [<short_stats_dir> <short_steps>]
+With the optional short trace (same command, fewer steps) the per-class table is the STEADY-STATE step: (long - short) / (steps
+difference), which removes model construction, first-use weight packing and other one-time launches from the per-step figures."""
 import collections
 import csv
 import glob
@@ -8,6 +10,7 @@ import json
 import sys
 
 stats_dir, pmc_prefix, tag, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+short_dir, short_steps = (sys.argv[5], int(sys.argv[6])) if len(sys.argv) > 6 else (None, 0)
 
 
 def load(pattern):
@@ -17,6 +20,8 @@ def load(pattern):
 def cls(n):
     if "wgrad_wino_kernel<2>" in n:
         return "wgrad_wino2d"
+    if "wino2d_x6" in n:
+        return "wino2d_x6"
     if "igemm_wino2d" in n:
         return "wino2d"
     return ("wgrad_wino" if "wgrad_wino" in n else "wgrad" if "wgrad" in n else "wino" if "wino" in n else "igemm" if "igemm" in n else "attn" if "attn" in n else "gn" if "::gn_" in n
@@ -33,16 +38,36 @@ with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
 by = collections.defaultdict(lambda: [0.0, 0])
 for r in rows:
     by[cls(r["Name"])][0] += float(r["TotalDurationNs"]); by[cls(r["Name"])][1] += int(r["Calls"])
+nsteps = steps
+if short_dir:
+    for r in load(short_dir + "/*/*_kernel_stats.csv"):
+        by[cls(r["Name"])][0] -= float(r["TotalDurationNs"]); by[cls(r["Name"])][1] -= int(r["Calls"])
+    nsteps = steps - short_steps
+tot_ss = sum(v[0] for v in by.values())
 md = [f"# rocprofv3 --kernel-trace --stats ({tag})", "",
       "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps %d --warmup 1 --profile-only` "
-      "(bs=128 fp32, full 216M-param CIFAR-10 UNet; %d training steps in the trace)." % (steps - 1, steps), "",
-      f"Total kernel time {tot / 1e6:.1f} ms = **{tot / 1e6 / steps:.1f} ms/step**.", "",
-      "| class | launches/step | ms/step | avg launch us |", "|---|---|---|---|"]
+      "(bs=128 fp32, full 216M-param CIFAR-10 UNet; %d training steps in the trace)." % (steps - 1, steps), ""]
+if short_dir:
+    md += [f"Steady state: the same command with {short_steps} steps is subtracted, so model construction, first-use weight packing and "
+           f"other one-time launches are out of the per-step figures below ({nsteps} steps remain).", ""]
+md += [f"Kernel time per steady-state step: **{tot_ss / 1e6 / nsteps:.1f} ms**, {sum(v[1] for v in by.values()) / nsteps:.0f} launches "
+       f"(whole trace: {tot / 1e6:.1f} ms).  The sum exceeds the wall-clock step of an untraced run because the tracer adds a "
+       "fixed cost to every dispatch and removes the overlap of the side-stream weight gradients with the main stream.", "",
+       "| class | launches/step | ms/step | avg launch us |", "|---|---|---|---|"]
 for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0]):
-    md.append(f"| {k} | {n / steps:.0f} | {t / 1e6 / steps:.2f} | {t / 1e3 / n:.1f} |")
-md += ["", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-for r in rows[:32]:
-    md.append(f"| `{r['Name'][:84]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    if n > 0:
+        md.append(f"| {k} | {n / nsteps:.0f} | {t / 1e6 / nsteps:.2f} | {t / 1e3 / n:.1f} |")
+per = collections.OrderedDict()
+for r in rows:
+    per[r["Name"]] = [float(r["TotalDurationNs"]), int(r["Calls"])]
+if short_dir:
+    for r in load(short_dir + "/*/*_kernel_stats.csv"):
+        if r["Name"] in per:
+            per[r["Name"]][0] -= float(r["TotalDurationNs"]); per[r["Name"]][1] -= int(r["Calls"])
+md += ["", "| kernel | launches/step | ms/step | avg us | % of kernel time |", "|---|---|---|---|---|"]
+for name, (t, n) in sorted(per.items(), key=lambda kv: -kv[1][0])[:36]:
+    if n > 0:
+        md.append(f"| `{name[:84]}` | {n / nsteps:.1f} | {t / 1e6 / nsteps:.2f} | {t / 1e3 / n:.1f} | {100 * t / tot_ss:.2f} |")
 
 # ---- PMC passes (each counter group collected in its own run, as MI355X_MICROARCH.md prescribes)
 cc = load(pmc_prefix + "GRBM_GUI_ACTIVE/*/*_counter_collection.csv")
