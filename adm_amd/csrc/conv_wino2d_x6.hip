@@ -28,8 +28,9 @@
 //         These waves also issue the weight DMA (their only global accesses: the explicit vmcnt wait before a barrier
 //         never touches the producers' prefetch);
 //       - barriers are s_barrier with LDS-scoped fences (lgkmcnt only): the producers' loads stay in flight across them.
-//   * LDS: A[2][4 ex][3 terms][64 tiles][16 ch] bf16 (2 x 24 KB) + B[3][4 ex][3 terms][64 couts][16 ch] (3 x 24 KB; weights are
-//     split once per optimiser step at pack time, adm_split3_bf16, and arrive by LDS-DMA two sub-stages ahead).  Rows are 32
+//   * LDS: A[2][4 ex][3 terms][64 tiles][16 ch] bf16 (2 x 24 KB) + B[4][4 ex][3 terms][64 couts][16 ch] (4 x 24 KB; weights are
+//     split once per optimiser step at pack time into the K-chunk-tiled layout of adm_split3_bf16 -- one contiguous KB per DMA
+//     instruction -- and arrive by LDS-DMA three stages ahead).  Rows are 32
 //     bytes with the two 16-byte halves of rows 8-15 (mod 16) swapped, so that the 16 lanes of a fragment-read group hit all 64 banks
 //     (un-swizzled: 40 % of the LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).
 // Replaces F.conv2d of Conv2d.forward and its autograd data gradient (/root/reference/unet/uncond_unet.py:98-110).
@@ -261,12 +262,12 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     const int row = (q & 1) * 32 + (lane >> 1);
     const int n = n0 + row;
     const int half = (lane ^ (row >> 3)) & 1;           // logical half stored at physical half (lane & 1)
-    b_voff[i] = (n < p.wrows) ? (unsigned)(((long)pt * p.plane + (long)n * p.Cin + half * 8) * 2) : OOB;
+    b_voff[i] = (n < p.wrows) ? (unsigned)((((long)pt * p.wrows + n) * 16 + half * 8) * 2) : OOB;
   }
   X6Seq lb; lb.init(chunks);
   int ld_slot = 0;
   auto issue_b = [&]() {                              // weights of the next stage of the sequence -> next ring slot
-    const int kb = (lb.ey * 12 * p.plane) * 2 + ((c_begin + lb.chunk()) << 5);   // ey block of twelve [ex][term] images; 32 bytes per chunk
+    const int kb = ((lb.ey * (p.Cin >> 4) + c_begin + lb.chunk()) * 12 * p.wrows) << 5;   // (ey, chunk) block of twelve [ex][term] images of wrows x 32 bytes
     unsigned short* dst = Bs + ld_slot * X6_B_STAGE + (wid * 6) * 512;           // 512 elements = one KB per instruction
     if (!(X6_ABL & 4)) {
 #pragma unroll
@@ -365,20 +366,27 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   }
 }
 
-// dst[img][term][i] = bf16 term `term` of src[img][i]   (img = Winograd plane; i over rows x cin)
-__global__ void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long per_img, int imgs) {
-  const long total = per_img * imgs;
+// Operand layout of the kernel: Wq6[ey][chunk][ex][term][n][16] -- the twelve 16-channel images a stage needs for its 64 rows are
+// 64 x 32 contiguous bytes each, so one LDS-DMA instruction reads one whole KB (plane-major rows would be 32-byte pieces of 32
+// different 128-byte lines per instruction).
+__global__ void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int rows, int cols) {
+  const long per = (long)rows * cols, total = per * 16;
+  const int chunks = cols >> 4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long img = i / per_img, k = i - img * per_img;
+    const int img = (int)(i / per);
+    const long rc = i - img * per;
+    const int n = (int)(rc / cols), c = (int)(rc - (long)n * cols);
+    const int ey = img >> 2, ex = img & 3;
     const float a = src[i];
     const unsigned u = __float_as_uint(a);
     const float r = a - __uint_as_float(u & 0xFFFF0000u);
     const unsigned m = __float_as_uint(r);
     const float r2 = r - __uint_as_float(m & 0xFFFF0000u);
-    unsigned short* d = dst + img * 3 * per_img + k;
+    unsigned short* d = dst + ((((long)(ey * chunks + (c >> 4)) * 12 + ex * 3) * rows + n) << 4) + (c & 15);
+    const long term = (long)rows << 4;
     d[0] = (unsigned short)(u >> 16);
-    d[per_img] = (unsigned short)(m >> 16);
-    d[2 * per_img] = (unsigned short)(__float_as_uint(r2) >> 16);
+    d[term] = (unsigned short)(m >> 16);
+    d[2 * term] = (unsigned short)(__float_as_uint(r2) >> 16);
   }
 }
 
@@ -387,18 +395,19 @@ __global__ void split3_kernel(const float* __restrict__ src, unsigned short* __r
 int adm_splitk_reduce(const float* ws, const float* bias, const float* res, float* y, long M, int N, int ldy, int ldr, int splitk,
                       hipStream_t stream);       // conv_igemm.hip
 
-// dst[imgs][3][per_img] (bf16 bit patterns) <- the exact three-term split of src[imgs][per_img] (f32)
-extern "C" int adm_split3_bf16(const float* src, void* dst, long per_img, int imgs, hipStream_t stream) {
-  if (!src || !dst || per_img <= 0 || imgs <= 0) return ADM_EINVAL;
-  const long total = per_img * imgs;
+// dst (bf16 bit patterns, 48 * rows * cols of them, layout [ey][cols/16][ex][term][rows][16]) <- the exact three-term split
+// a = a0 + a1 + a2 of the sixteen Winograd planes src[ey * 4 + ex][rows][cols] (f32); cols % 16 == 0
+extern "C" int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 15)) return ADM_EINVAL;
+  const long total = (long)rows * cols * 16;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(split3_kernel, dim3(grid), dim3(256), 0, stream, src, static_cast<unsigned short*>(dst), per_img, imgs);
+  hipLaunchKernelGGL(split3_kernel, dim3(grid), dim3(256), 0, stream, src, static_cast<unsigned short*>(dst), rows, cols);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
 
 // Same contract as adm_conv_fwd_wino2d, with wq6 = adm_split3_bf16 of the adm_pack_weight_wino2d operand (16 planes of
-// wrows x Cin): [16][3][wrows][Cin] bf16.
+// wrows x Cin).
 extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,
                                       long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                                       hipStream_t stream) {

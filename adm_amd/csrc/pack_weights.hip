@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
     }
   }
   // 2-D Winograd F(2x2, 3x3) operands (conv_wino2d.hip): U = G g G^T, plane ey * 4 + ex
-  // ... and their exact three-term bf16 splits [16][3][rows][cols] for conv_wino2d_x6.hip (columns 14, 15; 0 when unused)
+  // ... and their exact three-term bf16 splits in adm_split3_bf16's K-chunk-tiled layout for conv_wino2d_x6.hip (columns 14, 15; 0 when unused)
   float* __restrict__ wf2 = reinterpret_cast<float*>(t[12]);
   float* __restrict__ wb2 = reinterpret_cast<float*>(t[13]);
   unsigned short* __restrict__ wf6 = reinterpret_cast<unsigned short*>(t[14]);
@@ -200,10 +200,14 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
               const float r1 = u[ey] - __uint_as_float(b0 & 0xFFFF0000u);
               const unsigned b1 = __float_as_uint(r1);
               const float r2 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
-              unsigned short* d6 = dst6 + (long)(ey * 4 + ex) * 3 * plane2 + o;
+              // [ey][cols/16][ex][term][rows][16] with (rows, cols) = (Co_pad, Ci_pad) forward, (Ci_pad, Co_pad) data gradient
+              const int rows6 = which ? Ci_pad : Co_pad, cols6 = which ? Co_pad : Ci_pad;
+              const int n6 = which ? ci0 + ci_l : co0 + co_l, c6 = which ? co0 + co_l : ci0 + ci_l;
+              unsigned short* d6 = dst6 + ((((long)(ey * (cols6 >> 4) + (c6 >> 4)) * 12 + ex * 3) * rows6 + n6) << 4) + (c6 & 15);
+              const long term6 = (long)rows6 << 4;
               d6[0] = (unsigned short)(b0 >> 16);
-              d6[plane2] = (unsigned short)(b1 >> 16);
-              d6[2 * plane2] = (unsigned short)(__float_as_uint(r2) >> 16);
+              d6[term6] = (unsigned short)(b1 >> 16);
+              d6[2 * term6] = (unsigned short)(__float_as_uint(r2) >> 16);
             }
           }
         }

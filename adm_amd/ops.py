@@ -139,13 +139,13 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
 
 
 def _split_x6(ent: "_Packed"):
-    """[16][3][rows][cols] bf16 images of the 2-D Winograd operands: the exact three-term split a = a0 + a1 + a2."""
+    """bf16 images of the 2-D Winograd operands (K-chunk-tiled, see adm_split3_bf16): the exact three-term split a = a0 + a1 + a2."""
     for src, name in ((ent.w2f, "w2f6"), (ent.w2b, "w2b6")):
         dst = getattr(ent, name)
         if dst is None:
             dst = torch.empty((16, 3) + tuple(src.shape[1:]), device=src.device, dtype=torch.bfloat16)
             setattr(ent, name, dst)
-        call("adm_split3_bf16", ptr(src), ptr(dst), src.shape[1] * src.shape[2], 16)
+        call("adm_split3_bf16", ptr(src), ptr(dst), src.shape[1], src.shape[2])
 
 
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)

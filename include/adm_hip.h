@@ -100,14 +100,15 @@ int adm_pack_weight_wino2d(const float* w, float* wf, float* wb, int Co, int Ci,
 int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, const float* res, float* y, float* ws, long ws_floats,
                         int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, hipStream_t stream);
 /* f32 products on the bf16 MFMA through the exact three-term bf16 split (conv_wino2d_x6.hip): same contract as
- * adm_conv_fwd_wino2d with wq6 = adm_split3_bf16(adm_pack_weight_wino2d operand) = [16][3][wrows][Cin] bf16.
+ * adm_conv_fwd_wino2d with wq6 = adm_split3_bf16(adm_pack_weight_wino2d operand).
  * Replaces F.conv2d of Conv2d.forward + its data gradient (/root/reference/unet/uncond_unet.py:98-110). */
 int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,
                            long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                            hipStream_t stream);
 int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N);
-/* dst[imgs][3][per_img] bf16 <- exact split a = a0 + a1 + a2 of src[imgs][per_img] f32 */
-int adm_split3_bf16(const float* src, void* dst, long per_img, int imgs, hipStream_t stream);
+/* dst (48 * rows * cols bf16, layout [ey][cols/16][ex][term][rows][16]) <- exact split a = a0 + a1 + a2 of the sixteen Winograd
+ * planes src[ey * 4 + ex][rows][cols] (f32) */
+int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t stream);
 /* kernel variant of adm_conv_fwd_wino2d: -1 (default) chosen per launch, 1 wave-specialised (producer / consumer waves), 0 symmetric;
  * returns the old value */
 int adm_wino2d_variant(int ws);

@@ -215,7 +215,7 @@ def test_conv_x6_weights_follow_repack_all(ops, monkeypatch):
     assert not torch.equal(y0, y1)
     want = torch.empty_like(pk.w2f6)
     from adm_amd import hip as _hip
-    _hip.call("adm_split3_bf16", pk.w2f.data_ptr(), want.data_ptr(), pk.w2f.shape[1] * pk.w2f.shape[2], 16)
+    _hip.call("adm_split3_bf16", pk.w2f.data_ptr(), want.data_ptr(), pk.w2f.shape[1], pk.w2f.shape[2])
     assert torch.equal(want.view(torch.int16), pk.w2f6.view(torch.int16))
 
 

@@ -13,7 +13,7 @@ static void run(int B, int H, int Cin, int N, bool check) {
   float *x, *w, *y, *y2; void* w6;
   hipMalloc(&x, nx * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, ny * 4); hipMalloc(&y2, ny * 4); hipMalloc(&w6, nw * 6);
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
-  adm_split3_bf16(w, w6, (long)N * Cin, 16, 0);
+  adm_split3_bf16(w, w6, N, Cin, 0);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
   hipDeviceSynchronize();
