@@ -1,0 +1,337 @@
+// Weight gradient of the 3x3 stride-1 convs: transposed 2-D Winograd F(3x3, 2x2) (conv_wgrad_wino.hip, MODE 2) with the f32 products
+// carried on the bf16 MFMA through the exact three-term bf16 split of BOTH operands (see conv_wino2d_x6.hip for the arithmetic:
+// a = a0 + a1 + a2 exactly, six bf16 products per f32 product, f32 accumulation, error at the f32 MFMA's level).
+//
+//   per 2x2 tile of dY and the 4x4 patch of X around it:  a = A e A^T,  b = B^T d B,  m[ey][ex] = sum_tiles a[ey][ex] (x) b[ey][ex],
+//   dW = G^T m G.   As in the f32 kernel `ey` is gridDim.y: a workgroup reduces over TILES the y-combined rows
+//   (r0, r0 + r1, r0 - r1, -r1)[ey] of dY and (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey] of X through the x transforms (A e, B^T d), runs
+//   the four ex products, applies G^T along x in the epilogue and writes wx[co][ey][kx][ci]; adm_unpack_wgrad_wino2d applies G^T along y.
+//
+// The reduction index (tiles) is the K of the MFMA for both operands, and both arrive tile-major from HBM.  The f32 kernel
+// transposes them with 32 ds_write_b32 per thread and stage; here they stay tile-major in LDS ([tile][64 channels] bf16 rows of 192
+// bytes: 128 of data + 64 of padding, which makes the reads below conflict-free) and the consumer reads them TRANSPOSED with
+// ds_read_b64_tr_b16 (a 16-lane group gets 4 tiles x 16 channels column-major: lane i receives channel i of four consecutive
+// tiles, exactly the k-run a 32x32x16 operand lane needs; tools/tr_probe.hip).
+//
+// Wave-specialised like conv_wino2d_x6.hip (512 threads, one workgroup per CU):
+//   * waves 4-7 PRODUCE both operands: thread = (tile of the stage, 16-byte channel quad), a wave covers 4 tiles x 64 channels = four
+//     whole 256-byte runs per load instruction; loads of a stage (<= 4 of dY, 8 of X) are issued three stages ahead into one of three
+//     register sets; y combination, x transform (f32), three-term split, 24 ds_write_b64 per stage;
+//   * waves 0-3 CONSUME: 32 couts x 32 cins x 4 ex each; per stage 48 transposed fragment reads and 24 MFMAs.  The MFMA accumulators
+//     run over four stages (<= 24 matrix adds from C = 0) and are then added to the running totals with f32 adds (the long sums see
+//     rounded f32 adds, not truncating matrix adds);
+//   * one s_barrier per stage with LDS-only counters: the producers' loads stay in flight across it.
+// Replaces the autograd weight gradient of Conv2d.forward (/root/reference/unet/uncond_unet.py:98-110).
+#include <algorithm>
+#include "common.h"
+#include "../../include/adm_hip.h"
+
+namespace {
+
+struct WxP {
+  const float* x; const float* dy; float* dwp; float* dbias;
+  int Pp, H, W, lw, Cin, ldx, Cout, lddy, tilesN, chunk, atomic, xbytes, dybytes;     // Pp = 2x2 tiles in all; chunk = tiles per split
+  long split_stride, bias_stride;      // > 0: deterministic mode, partials of split z at dwp + z * split_stride (plain stores)
+};
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+constexpr int XT = 64, XK = 16;                    // 64 x 64 channel tile, 16 tiles (2x2 pixels each) per stage
+constexpr int XROW = 96;                           // bf16 elements per LDS row: 64 channels + 32 of padding (192 bytes)
+constexpr int X_IMG = 4 * 3 * XK * XROW;           // one operand image of a stage: [4 ex][3 terms][16 tiles][XROW] = 36 KB
+constexpr int X_FOLD = 4;                          // stages per accumulator run
+
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 sub4x(f32x4 a, f32x4 b) {
+  const f32x2 lo = pk_sub2(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub2(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+// v = v0 + v1 + v2 exactly, each term a bf16 (packed top halves: two dwords per term for the four channels)
+__device__ __forceinline__ void split3x(const f32x4 v, u32x2& t0, u32x2& t1, u32x2& t2) {
+  f32x4 h, mh;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) h[i] = __uint_as_float(__float_as_uint(v[i]) & 0xFFFF0000u);
+  const f32x4 r = sub4x(v, h);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mh[i] = __uint_as_float(__float_as_uint(r[i]) & 0xFFFF0000u);
+  const f32x4 r2 = sub4x(r, mh);
+  t0 = u32x2{__builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u),
+             __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u)};
+  t1 = u32x2{__builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u),
+             __builtin_amdgcn_perm(__float_as_uint(r[3]), __float_as_uint(r[2]), 0x07060302u)};
+  t2 = u32x2{__builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u),
+             __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u)};
+}
+__device__ __forceinline__ void store_planes(const f32x4 (&v)[4], unsigned short* l) {
+#pragma unroll
+  for (int ex = 0; ex < 4; ++ex) {
+    u32x2 t0, t1, t2;
+    split3x(v[ex], t0, t1, t2);
+    *reinterpret_cast<u32x2*>(l + (ex * 3 + 0) * XK * XROW) = t0;
+    *reinterpret_cast<u32x2*>(l + (ex * 3 + 1) * XK * XROW) = t1;
+    *reinterpret_cast<u32x2*>(l + (ex * 3 + 2) * XK * XROW) = t2;
+  }
+}
+__device__ __forceinline__ void lds_barrier() {    // waits for this wave's LDS traffic only
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smx[];
+  unsigned short* As = smx;                        // [2][X_IMG]  dY side: rows = tiles, columns = couts
+  unsigned short* Bs = smx + 2 * X_IMG;            // [2][X_IMG]  X side:  rows = tiles, columns = cins
+  const int tid = threadIdx.x, lane = tid & 63, hw_wid = tid >> 6;
+  const bool producer = hw_wid >= 4;
+  const int wid = hw_wid & 3;
+  const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+  const int co0 = tm * XT, ci0 = tn * XT;
+  const int ey = blockIdx.y;
+  const int pbeg = blockIdx.z * p.chunk;
+  const int pend = min(p.Pp, pbeg + p.chunk);
+  if (pbeg >= pend) return;                        // (whole workgroup)
+  const int KT = (pend - pbeg + XK - 1) / XK;      // stages
+  constexpr unsigned OOB = 0x80000000u;
+
+  if (producer) {
+    // ================================================================ both operands
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
+    const int tl = wid * 4 + (lane >> 4), quad = lane & 15;       // tile of the stage, channel quad
+    const unsigned a_col = (co0 + quad * 4 < p.Cout) ? (unsigned)(co0 + quad * 4) * 4u : OOB;
+    const unsigned b_col = (ci0 + quad * 4 < p.Cin) ? (unsigned)(ci0 + quad * 4) * 4u : OOB;
+    const int Wh = p.W >> 1, Hh = p.H >> 1, lwh = p.lw - 1;
+    const unsigned ystep = (unsigned)p.lddy * 4u, yrow = (unsigned)p.W * ystep;
+    const unsigned xstep = (unsigned)p.ldx * 4u;
+    const int iA = (ey == 0) ? 0 : 1, iB = (ey == 3) ? 3 : 2;       // X rows of this pass: (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey]
+    constexpr int D = 3;                           // stages in flight
+    f32x4 t0[D][2], t1[D][2], u0[D][4], u1[D][4];
+    auto issue = [&](int d, int s) {               // loads of stage s -> register set d (stages past the end read nothing)
+      const int pr = pbeg + s * XK + tl;
+      const bool pv = pr < pend && s < KT;
+      const int xp = pr & (Wh - 1), ty = (pr >> lwh) & (Hh - 1);
+      const unsigned pix = ((unsigned)(pr >> lwh) << (p.lw + 1)) + 2u * (unsigned)xp;      // top-left output pixel of the tile
+      // dY rows 2ty (r0) and 2ty + 1 (r1): a_y = (r0, r0 + r1, r0 - r1, -r1)[ey]; a row the pass does not use is read out of range
+      const unsigned ya = (pv && a_col != OOB) ? pix * ystep + a_col : OOB;
+      const unsigned y0 = (ey != 3) ? ya : OOB, y1 = (ey != 0 && ya != OOB) ? ya + yrow : OOB;
+      t0[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y0, 0, 0));
+      t0[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y0 != OOB ? y0 + ystep : OOB), 0, 0));
+      t1[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y1, 0, 0));
+      t1[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y1 != OOB ? y1 + ystep : OOB), 0, 0));
+      const bool vA = pv && b_col != OOB && (iA != 0 || ty > 0), vB = pv && b_col != OOB && (iB != 3 || ty < Hh - 1);
+      const unsigned xa = pix * xstep + b_col + (unsigned)((iA - 1) * p.W - 1) * xstep;      // row iA, column 2xp - 1 (may wrap: masked)
+      const unsigned xb = pix * xstep + b_col + (unsigned)((iB - 1) * p.W - 1) * xstep;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool cv = (j != 0 || xp > 0) && (j != 3 || xp < Wh - 1);
+        u0[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vA && cv) ? xa + j * xstep : OOB), 0, 0));
+        u1[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vB && cv) ? xb + j * xstep : OOB), 0, 0));
+      }
+    };
+    // the bias gradient = sum of every dY pixel = the ex = 1 component (e0 + e1 along x) of the ey = 1 workgroups (r0 + r1 along y)
+    const bool do_bias = p.dbias != nullptr && tn == 0 && ey == 1;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    unsigned short* la = As + tl * XROW + quad * 4;
+    unsigned short* lb = Bs + tl * XROW + quad * 4;
+    auto store = [&](int d, int slot) {            // y combination, x transforms, split, into slot
+      f32x4 e[2], dd[4];
+      if (ey <= 1) { e[0] = t0[d][0] + t1[d][0]; e[1] = t0[d][1] + t1[d][1]; }     // the unused row was read as zeros
+      else { e[0] = sub4x(t0[d][0], t1[d][0]); e[1] = sub4x(t0[d][1], t1[d][1]); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dd[j] = (ey == 1) ? u0[d][j] + u1[d][j] : (ey == 2) ? sub4x(u1[d][j], u0[d][j]) : sub4x(u0[d][j], u1[d][j]);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 a[4] = {e[0], e[0] + e[1], sub4x(e[0], e[1]), sub4x(zero, e[1])};
+      const f32x4 b[4] = {sub4x(dd[0], dd[2]), dd[1] + dd[2], sub4x(dd[2], dd[1]), sub4x(dd[1], dd[3])};
+      if (do_bias) bsum += a[1];
+      store_planes(a, la + slot * X_IMG);
+      store_planes(b, lb + slot * X_IMG);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+    // barrier s separates "images(s) written" from compute(s); images(s) live in slot s & 1; set s % D is refilled with stage s + D
+    for (int s0 = 0; s0 < KT; s0 += 2 * D) {       // 2 D = 6 stages per trip: static register sets and slots
+#pragma unroll
+      for (int k = 0; k < 2 * D; ++k) {
+        if (s0 + k < KT) {                         // (uniform)
+          store(k % D, k & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(k % D, s0 + k + D);
+          __builtin_amdgcn_sched_barrier(0);
+          lds_barrier();
+        }
+      }
+    }
+    if (do_bias) {     // lanes l, l + 16, l + 32, l + 48 of a wave hold four tiles of the same channel quad; four producer waves
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bsum[j] += __shfl_xor(bsum[j], 16, 64); bsum[j] += __shfl_xor(bsum[j], 32, 64); }
+      float* red = reinterpret_cast<float*>(smx);  // every image has been consumed: the consumers are past the last barrier ...
+      lds_barrier();                               // ... once they arrive here (they make the same two extra barriers)
+      if (lane < 16) *reinterpret_cast<f32x4*>(red + (wid * 16 + lane) * 4) = bsum;
+      lds_barrier();
+      if (wid == 0 && lane < 16 && a_col != OOB) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(red + lane * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * 16 + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.split_stride > 0) p.dbias[(long)blockIdx.z * p.bias_stride + co0 + quad * 4 + j] = v[j];
+          else atomicAdd(&p.dbias[co0 + quad * 4 + j], v[j]);
+        }
+      }
+    }
+    return;
+  }
+
+  // ================================================================== consumer waves
+  const int wm = wid >> 1, wn = wid & 1;           // 32-cout block, 32-cin block
+  // transposed fragment read: 16-lane group g, lane i = 4 q + p of it: row (tile) 8 (g >> 1) + q [+ 4 for the second read],
+  // columns 16 (g & 1) + 4 p .. + 3 of the wave's 32-channel block; the lane receives channel 16 (g & 1) + i of those four tiles
+  const int g = lane >> 4, gi = lane & 15;
+  const int fr = (8 * (g >> 1) + (gi >> 2)) * XROW + 16 * (g & 1) + 4 * (gi & 3);
+  const int a_foff = fr + wm * 32, b_foff = fr + wn * 32;
+  f32x16 acc[4], tot[4];
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[xi][r] = 0.f;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto frag = [&](const unsigned short* base) -> bf16x8 {
+    struct { s16x4 lo, hi; } v;
+    v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * XROW));
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  int run = 0;
+  for (int s = 0; s < KT; ++s) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const unsigned short* Ab = As + (s & 1) * X_IMG + a_foff;
+    const unsigned short* Bb = Bs + (s & 1) * X_IMG + b_foff;
+    const bool first = run == 0;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      bf16x8 a[3], b[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        a[k] = frag(Ab + (xi * 3 + k) * XK * XROW);
+        b[k] = frag(Bb + (xi * 3 + k) * XK * XROW);
+      }
+      f32x16 c;
+      if (first) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], zero, 0, 0, 0);       // (wave-uniform branch)
+      else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[xi], 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    }
+    if (++run == X_FOLD || s + 1 == KT) {
+      run = 0;
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) tot[xi] += acc[xi];
+    }
+  }
+  if (p.dbias != nullptr && tn == 0 && ey == 1) {  // the producers' bias reduction uses two more barriers
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+  }
+
+  // ---- epilogue: G^T along x.  C/D layout: col = lane & 31 (cin), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (cout)
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ci = ci0 + wn * 32 + lr;
+  if (ci >= p.Cin) return;
+  const int cb = co0 + wm * 32 + 4 * lh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = cb + (r & 3) + 8 * (r >> 2);
+    if (co >= p.Cout) continue;
+    const float h = 0.5f * (tot[1][r] + tot[2][r]);
+    const float w0 = tot[0][r] + h, w1 = 0.5f * (tot[1][r] - tot[2][r]), w2 = h + tot[3][r];
+    float* dst = p.dwp + (long)blockIdx.z * p.split_stride + ((long)co * 12 + ey * 3) * p.Cin + ci;
+    if (p.atomic) {
+      atomicAdd(dst, w0); atomicAdd(dst + p.Cin, w1); atomicAdd(dst + 2 * p.Cin, w2);
+    } else {
+      dst[0] = w0; dst[p.Cin] = w1; dst[2 * p.Cin] = w2;
+    }
+  }
+}
+
+int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
+                  int lddy, int splits, bool det, bool plan_only, hipStream_t stream) {
+  if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
+  if (B <= 0 || H < 2 || W < 2) return ADM_EINVAL;
+  if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
+  if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
+  auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  const int lw = ilog2(W), lh = ilog2(H);
+  if (lw < 1 || lh < 1) return ADM_EINVAL;                    // power-of-two H, W (>= 2) only
+  WxP p;
+  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
+  const long P = (long)B * H * W;
+  const long xb = P * ldx * 4, db = P * lddy * 4;
+  if (xb >= (1L << 31) - (1L << 22) || db >= (1L << 31) - (1L << 22)) return ADM_EINVAL;   // 32-bit offsets
+  p.Pp = (int)(P / 4); p.H = H; p.W = W; p.lw = lw; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
+  p.xbytes = (int)xb; p.dybytes = (int)db;
+  p.tilesN = adm_cdiv(Cin, XT);
+  const long tiles = (long)adm_cdiv(Cout, XT) * p.tilesN * 4;
+  if (splits <= 0) {
+    // one workgroup per CU: 256 slots.  The split count whose workgroup total fills whole rounds best, with a mild preference for
+    // fewer splits; >= 96 tiles (6 stages) per split
+    const long slots = 256;
+    const int maxs = (int)std::min<long>((p.Pp + 95) / 96, 64);
+    double best = -1.0;
+    splits = 1;
+    for (int sN = 1; sN <= maxs; ++sN) {
+      const long wgs = tiles * sN;
+      const long rounds = (wgs + slots - 1) / slots;
+      const double fill = (double)wgs / (double)(rounds * slots) - 0.002 * sN;
+      if (fill > best + 1e-9) { best = fill; splits = sN; }
+    }
+  }
+  int chunk = ((p.Pp + splits - 1) / splits + XK - 1) / XK * XK;
+  splits = (p.Pp + chunk - 1) / chunk;
+  if (plan_only) return splits;
+  p.chunk = chunk;
+  p.split_stride = det ? (long)Cout * 12 * Cin : 0;
+  p.bias_stride = det ? Cout : 0;
+  p.atomic = splits > 1 && !det;
+  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 12 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
+  constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+        hipSuccess)
+      return ADM_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(adm_cdiv(Cout, XT) * p.tilesN, 4, splits);
+  hipLaunchKernelGGL(wgrad_x6_kernel, grid, dim3(512), smem, stream, p);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+}  // namespace
+
+// Same contract as adm_conv_wgrad_wino2d: dwp2[Cout][4 ey][3 kx][Cin] x-folded planes (adm_unpack_wgrad_wino2d applies G^T along y),
+// dbias += column sums of dy; splits = 0 picks the split count; H and W powers of two >= 2.
+extern "C" int adm_conv_wgrad_x6(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx,
+                                 int Cout, int lddy, int splits, hipStream_t stream) {
+  return wgrad_x6_impl(x, dy, dwp2, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, false, false, stream);
+}
+// Deterministic workspace mode: split z writes its partial planes to ws[z][Cout][12][Cin] and its bias partial to bws[z][Cout]
+// (plain stores); splits must be adm_conv_wgrad_x6_plan(...)
+extern "C" int adm_conv_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx,
+                                    int Cout, int lddy, int splits, hipStream_t stream) {
+  return wgrad_x6_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, true, false, stream);
+}
+extern "C" int adm_conv_wgrad_x6_plan(int B, int H, int W, int Cin, int Cout) {
+  return wgrad_x6_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, 0, false, true, nullptr);
+}

@@ -421,23 +421,29 @@ class _Conv(torch.autograd.Function):
                 wmode = 2 if wino2_w else int(wino_w)
                 planes = 12 if wino2_w else ks * ks
                 det = DETERMINISTIC and not bf16
+                x6_w = wino2_w and BF16X6          # f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip)
                 splits = 1
                 if det:        # splits store partial tiles to a workspace; the unpack launch sums them in a fixed order
-                    splits = hip.lib().adm_conv_wgrad_plan(B, Ho, Wo, cip, cop, ks, int(up), wmode)
+                    splits = (hip.lib().adm_conv_wgrad_x6_plan(B, Ho, Wo, cip, cop) if x6_w else
+                              hip.lib().adm_conv_wgrad_plan(B, Ho, Wo, cip, cop, ks, int(up), wmode))
                     if splits < 1:
                         raise RuntimeError(f"adm_conv_wgrad_plan failed with code {splits}")
                     dwp = _new((splits, cop, planes * cip), dy)
                     bws = _new((splits, cop), dy) if dbp is not None else None
                 else:
                     dwp = _new((cop, planes * cip), dy)
-                kind = "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
+                kind = "wgrad_wino2x6" if x6_w else "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
                 with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"{kind.replace('_', '-')} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16:
                         call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+                    elif det and x6_w:
+                        call("adm_conv_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, splits)
                     elif det:
                         call("adm_conv_wgrad_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, ks, int(up),
                              splits, wmode)
+                    elif x6_w:
+                        call("adm_conv_wgrad_x6", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, 0)
                     elif wino2_w:
                         call("adm_conv_wgrad_wino2d", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, 0)
                     elif wino_w:

@@ -109,6 +109,16 @@ int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N);
 /* dst (48 * rows * cols bf16, layout [ey][cols/16][ex][term][rows][16]) <- exact split a = a0 + a1 + a2 of the sixteen Winograd
  * planes src[ey * 4 + ex][rows][cols] (f32) */
 int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t stream);
+/* The 2-D Winograd weight gradient with the f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip): same
+ * contract as adm_conv_wgrad_wino2d (dwp2[Cout][4 ey][3 kx][Cin] -> adm_unpack_wgrad_wino2d; dbias += column sums of dy; splits = 0:
+ * chosen by the launcher; H, W powers of two >= 2).  _ws: deterministic mode, split z stores its partial planes at ws[z][Cout][12][Cin]
+ * and its bias partial at bws[z][Cout]; splits must be adm_conv_wgrad_x6_plan(...).
+ * Replaces the autograd weight gradient of Conv2d.forward (/root/reference/unet/uncond_unet.py:98-110). */
+int adm_conv_wgrad_x6(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
+                      int lddy, int splits, hipStream_t stream);
+int adm_conv_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
+                         int lddy, int splits, hipStream_t stream);
+int adm_conv_wgrad_x6_plan(int B, int H, int W, int Cin, int Cout);
 /* kernel variant of adm_conv_fwd_wino2d: -1 (default) chosen per launch, 1 wave-specialised (producer / consumer waves), 0 symmetric;
  * returns the old value */
 int adm_wino2d_variant(int ws);

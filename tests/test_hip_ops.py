@@ -271,11 +271,22 @@ def test_conv_wgrad_winograd_op_level(ops, monkeypatch, B, cin, cout, H, W, up, 
     y = ops.conv2d(xd, wd, bd, None, up=up)
     (y * nhwc(pad_c(gy, cop))).sum().backward()
     kinds = [r[0] for r in ops.PROFILE]
-    # even-height, non-upsampled shapes take the 2-D F(3x3,2x2) form (conv_wgrad_wino.hip MODE 2), the others the 1-D F(3,2) form
-    assert kinds.count("wgrad_wino2" if (not up and H >= 2) else "wgrad_wino") == 1 and "wgrad" not in kinds, kinds
+    # even-height, non-upsampled shapes take the 2-D F(3x3,2x2) form -- by default with the f32 products on the bf16 MFMA
+    # (conv_wgrad_x6.hip) --, the others the 1-D F(3,2) form
+    two_d = not up and H >= 2
+    assert kinds.count("wgrad_wino2x6" if two_d else "wgrad_wino") == 1 and "wgrad" not in kinds, kinds
     close(wd.grad, wr.grad)
     close(bd.grad, br.grad)
-    monkeypatch.setattr(ops, "WINOGRAD2D", False)              # ... and the 1-D form on the same problem
+    if two_d:                                                  # ... the f32-MFMA 2-D form (ADM_BF16X6=0) on the same problem
+        monkeypatch.setattr(ops, "BF16X6", False)
+        wd1, bd1 = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+        monkeypatch.setattr(ops, "PROFILE", [])
+        y1 = ops.conv2d(xd, wd1, bd1, None, up=up)
+        (y1 * nhwc(pad_c(gy, cop))).sum().backward()
+        assert [r[0] for r in ops.PROFILE].count("wgrad_wino2") == 1
+        close(wd1.grad, wr.grad)
+        close(bd1.grad, br.grad)
+    monkeypatch.setattr(ops, "WINOGRAD2D", False)              # ... and the 1-D form
     wd2, bd2 = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     monkeypatch.setattr(ops, "PROFILE", [])
     y2 = ops.conv2d(xd, wd2, bd2, None, up=up)

@@ -10,20 +10,23 @@ static void run(int B, int H, int Cin, int N, bool check) {
   std::vector<float> hx(nx), hw(nw);
   for (auto& v : hx) v = (rand() / (float)RAND_MAX) * 2 - 1;
   for (auto& v : hw) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.02f;
-  float *x, *w, *y, *y2; void* w6;
+  float *x, *w, *y, *y2, *ws = nullptr; void* w6;
+  long wsn = (long)adm_wino2d_x6_splitk(B, H, H, Cin, N) * ny;
+  if (wsn < (long)ny * 2 || getenv("X6_NOSPLIT")) wsn = 0;
   hipMalloc(&x, nx * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, ny * 4); hipMalloc(&y2, ny * 4); hipMalloc(&w6, nw * 6);
+  if (wsn) hipMalloc(&ws, wsn * 4);
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
   adm_split3_bf16(w, w6, N, Cin, 0);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
+  for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, 0);
   hipDeviceSynchronize();
   const int reps = 20;
   hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
+  for (int i = 0; i < reps; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, 0);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   double fl = 2.0 * B * H * H * (double)N * 9 * Cin;
-  printf("x6 ABL=%d B=%d H=%d Cin=%d N=%d: %.3f ms  %.1f TFLOP/s algorithmic", X6_ABL, B, H, Cin, N, ms, fl / ms / 1e9);
+  printf("x6 split=%d ABL=%d B=%d H=%d Cin=%d N=%d: %.3f ms  %.1f TFLOP/s algorithmic", wsn ? (int)(wsn / ny) : 1, X6_ABL, B, H, Cin, N, ms, fl / ms / 1e9);
   if (check) {
     adm_conv_fwd_wino2d(x, w, nullptr, nullptr, y2, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
     std::vector<float> a(ny), b(ny);
@@ -45,6 +48,9 @@ int main() {
   run(128, 32, 192, 192, false);
   run(128, 16, 384, 384, false);
   run(128, 16, 768, 384, false);
-  run(128, 8, 384, 384, false);
+  run(128, 8, 384, 384, true);
+  run(128, 8, 768, 384, false);
+  run(128, 4, 384, 384, true);
+  run(128, 4, 768, 384, false);
   return 0;
 }

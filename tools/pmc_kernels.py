@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(glob.glob(d + "/*/*_counter_collection.csv")[0])
 
 
 def cls(n):
-    for key in ("wino2d_x6", "wino2d", "wgrad_wino", "wgrad_f32", "igemm_wino", "igemm_f32", "attn_", "gn_"):
+    for key in ("wgrad_x6", "wino2d_x6", "wino2d", "wgrad_wino", "wgrad_f32", "igemm_wino", "igemm_f32", "attn_", "gn_"):
         if key in n:
             return key
     return "other"
