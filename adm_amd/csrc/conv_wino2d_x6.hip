@@ -48,6 +48,7 @@ struct X6P {
   const float* x; const unsigned short* w; const float* bias; const float* res; float* y;
   int Mt, N, H, W, Hh, Wh, Cin, ldx, ldy, ldr, wrows, tilesN, xbytes, wbytes, plane;   // plane = wrows * Cin (elements of one [term] image)
   int splitk, chunks_per_split; float* ws;
+  int ybytes, rbytes;                  // > 0: y / res fit 32-bit byte offsets (branch-free buffer epilogue)
 };
 
 typedef __attribute__((address_space(3))) void x6_lds_void;
@@ -252,6 +253,8 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   if (p.splitk > 1) {
     p.y = p.ws + (long)blockIdx.y * ((long)p.Mt * 4) * p.N;
     p.ldy = p.N; p.bias = nullptr; p.res = nullptr;
+    const long sb = (long)p.Mt * 4 * p.N * 4;
+    p.ybytes = sb < (1L << 31) ? (int)sb : 0;
   }
   // B loader (LDS-DMA): 24 one-KB instructions per stage = (ex, term) image pt x 32-row half; wave w issues q = 6w .. 6w+5.
   // Lane l of an instruction covers row (q & 1) * 32 + (l >> 1), 16-byte half (l & 1) of the 32-byte row.
@@ -345,9 +348,41 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 
   // ---- epilogue.  C/D layout col = lane&31 (cout), row = (r&3) + 8 (r>>2) + 4 (lane>>5) (tile)
   const int n = n0 + wn * 32 + lr;
-  if (n >= p.N) return;
-  const float bv = p.bias ? p.bias[n] : 0.f;
+  const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
   const int tb = mt0 + wm * 32 + 4 * lh;
+  if (p.ybytes > 0) {
+    // branch-free: residual loads and output stores through buffer descriptors, masked lanes at an out-of-range offset (a missing
+    // residual = an empty descriptor: reads return 0).  With `if`s per element the compiler serialises the 64 residual loads of a
+    // thread, each waiting for the previous one -- tens of microseconds per workgroup.
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.rbytes : 0, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = tb + (r & 3) + 8 * (r >> 2);
+      const bool ok = t < p.Mt && n < p.N;
+      const int xp = t % p.Wh;
+      const int u = t / p.Wh;                      // = b * Hh + ty
+      const unsigned px0 = ((unsigned)u * 2u) * (unsigned)p.W + 2u * (unsigned)xp;     // pixel (b, 2ty, 2xp): (b*H + 2ty) * W + 2xp
+      unsigned oy[2][2], orr[2][2];
+      float rv[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned px = px0 + (unsigned)a * (unsigned)p.W + (unsigned)c;
+          oy[a][c] = ok ? (px * (unsigned)p.ldy + (unsigned)n) * 4u : OOB;
+          orr[a][c] = ok ? (px * (unsigned)p.ldr + (unsigned)n) * 4u : OOB;
+          rv[a][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)orr[a][c], 0, 0));
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, Y[a][c][r] + bv + rv[a][c]), rs_y, (int)oy[a][c], 0, 0);
+    }
+    return;
+  }
+  if (n >= p.N) return;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int t = tb + (r & 3) + 8 * (r >> 2);
@@ -423,6 +458,9 @@ extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const flo
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin;
   p.tilesN = adm_cdiv(N, X6N);
   p.splitk = 1; p.chunks_per_split = 0; p.ws = nullptr;
+  const long yb = (long)B * H * W * ldy * 4, rb = res ? (long)B * H * W * ldr * 4 : 0;
+  p.ybytes = (yb < (1L << 31) && rb < (1L << 31)) ? (int)yb : 0;
+  p.rbytes = (int)rb;
   const int sk = (ws && !(N & 3) && !(ldy & 3) && (!res || !(ldr & 3))) ? adm_wino2d_x6_splitk(B, H, W, Cin, N) : 1;
   if (sk > 1 && ws_floats >= (long)sk * Mt * 4 * N) {
     const int chunks = Cin >> 4;

@@ -33,6 +33,8 @@ _SIGS = {
     "adm_conv_fwd_wino2d_x6": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P],
     "adm_wino2d_x6_splitk": [I, I, I, I, I],
     "adm_split3_bf16": [P, P, I, I, P],
+    "adm_gemm_x6": [P, P, P, P, P, L, I, I, I, I, I, I, P],
+    "adm_split3_rows": [P, P, I, I, I, P],
     "adm_conv_wgrad_x6": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_x6_ws": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_x6_plan": [I, I, I, I, I],

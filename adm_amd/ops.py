@@ -61,7 +61,7 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 # packed-weight cache
 # ------------------------------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "w2f6", "w2b6", "src")
+    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "w2f6", "w2b6", "g6f", "g6b", "src")
 
 
 # Contraction precision of the conv / Linear kernels: "f32" (default: exact fp32 MFMA) or "bf16" (BASELINE
@@ -138,6 +138,28 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
     return ent.w2f, ent.w2b
 
 
+GEMM_X6_MIN_M = 8192
+
+
+def _use_gemm_x6(M: int, ks: int, up, n_p: int, k_p: int) -> bool:
+    """1x1 convs with many pixels run on conv_gemm_x6.hip (f32 products on the bf16 MFMA, exact three-term split)."""
+    return BF16X6 and ks == 1 and not up and M >= GEMM_X6_MIN_M and n_p % 128 == 0 and k_p % 32 == 0
+
+
+def _gemm_x6_operands(ent: "_Packed"):
+    """[K/16][3][rows][16] bf16 images of a packed 1x1 operand pair (forward: rows = couts; data gradient: rows = cins)."""
+    if ent.g6f is None:
+        ent.g6f = torch.empty((3,) + tuple(ent.fwd.shape), device=ent.fwd.device, dtype=torch.bfloat16)
+        ent.g6b = torch.empty((3,) + tuple(ent.bwd.shape), device=ent.bwd.device, dtype=torch.bfloat16)
+        _resplit_gemm_x6(ent)
+    return ent.g6f, ent.g6b
+
+
+def _resplit_gemm_x6(ent: "_Packed"):
+    for src, dst in ((ent.fwd, ent.g6f), (ent.bwd, ent.g6b)):
+        call("adm_split3_rows", ptr(src), ptr(dst), src.shape[0], src.shape[1], src.shape[1])
+
+
 def _split_x6(ent: "_Packed"):
     """bf16 images of the 2-D Winograd operands (K-chunk-tiled, see adm_split3_bf16): the exact three-term split a = a0 + a1 + a2."""
     for src, name in ((ent.w2f, "w2f6"), (ent.w2b, "w2b6")):
@@ -170,6 +192,7 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     ent.wf = ent.wb = None
     ent.w2f = ent.w2b = None
     ent.w2f6 = ent.w2b6 = None
+    ent.g6f = ent.g6b = None
     ent.src = (co, ci, ks, qkv)
     ent.fwd = _new((cop, ks * ks * cip), w)
     ent.bwd = _new((cip, ks * ks * cop), w)
@@ -244,6 +267,8 @@ def repack_all():
         if b is not None and (qkv or ceil32(co) != co):
             call("adm_permute_vec", ptr(b.detach()), ptr(ent.bias), co, ceil32(co), int(qkv), 0)
         ent.fwd16 = ent.bwd16 = None
+        if ent.g6f is not None:
+            _resplit_gemm_x6(ent)
         ent.key = (w.data_ptr(), w._version, _pack_epoch, ks, qkv, None if b is None else (b.data_ptr(), b._version))
 
 
@@ -366,10 +391,14 @@ class _Conv(torch.autograd.Function):
         wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv
         wq2 = _wino2_operands(weight, pk)[0] if (wino and _use_wino2d(B, Ho, Wo, ks, up, tile)) else None
         wq = _wino_operands(weight, pk)[0] if (wino and wq2 is None) else None
-        kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "igemm"
+        g6 = not use_bf16 and _use_gemm_x6(B * Ho * Wo, ks, up, cop, cip)
+        kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
         with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                    f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
-            if use_bf16:
+            if g6:
+                call("adm_gemm_x6", ptr(x), ptr(_gemm_x6_operands(pk)[0]), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
+                     cop, cop, cop)
+            elif use_bf16:
                 call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
                      Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
@@ -500,10 +529,14 @@ class _Conv(torch.autograd.Function):
             wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, False, -1) and not qkv
             wq2 = _wino2_operands(weight, pk)[1] if (wino and _use_wino2d(B, Ho, Wo, ks, False, -1)) else None
             wq = _wino_operands(weight, pk)[1] if (wino and wq2 is None) else None
-            kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "igemm"
+            g6 = not use_bf16 and _use_gemm_x6(B * Ho * Wo, ks, up, cip, cop)
+            kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
             with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                        f"dgrad{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
-                if use_bf16:
+                if g6:
+                    call("adm_gemm_x6", ptr(dy), ptr(_gemm_x6_operands(pk)[1]), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
+                         cip, cip)
+                elif use_bf16:
                     call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
                          cop, cop, cip, cip, cip, cip, ks, 0, -1)
                 else:

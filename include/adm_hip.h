@@ -109,6 +109,12 @@ int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N);
 /* dst (48 * rows * cols bf16, layout [ey][cols/16][ex][term][rows][16]) <- exact split a = a0 + a1 + a2 of the sixteen Winograd
  * planes src[ey * 4 + ex][rows][cols] (f32) */
 int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t stream);
+/* 1x1 conv / pixel-wise linear map with the f32 products on the bf16 MFMA by exact three-term splitting (conv_gemm_x6.hip):
+ * y[M][ldy] = x[M][ldx] (K channels) . w^T (+ bias) (+ res), w6 = adm_split3_rows of the packed operand [wrows >= N][K] (f32, row
+ * stride ld) = [K/16][3][wrows][16] bf16.  K % 32 == 0.  Replaces F.conv2d (1x1) + its data gradient (uncond_unet.py:98-110). */
+int adm_gemm_x6(const float* x, const void* w6, const float* bias, const float* res, float* y, long M, int K, int ldx, int N, int wrows,
+                int ldy, int ldr, hipStream_t stream);
+int adm_split3_rows(const float* src, void* dst, int rows, int cols, int ld, hipStream_t stream);
 /* The 2-D Winograd weight gradient with the f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip): same
  * contract as adm_conv_wgrad_wino2d (dwp2[Cout][4 ey][3 kx][Cin] -> adm_unpack_wgrad_wino2d; dbias += column sums of dy; splits = 0:
  * chosen by the launcher; H, W powers of two >= 2).  _ws: deterministic mode, split z stores its partial planes at ws[z][Cout][12][Cin]

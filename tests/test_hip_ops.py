@@ -194,6 +194,47 @@ def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
     close(wd.grad, wr.grad)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,qkv,with_res", [(8, 384, 1152, 32, True, False), (8, 384, 384, 32, False, True), (9, 192, 384, 31, False, False),
+                                                        (16, 768, 128, 24, False, True)])
+def test_conv1x1_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, qkv, with_res):
+    """1x1 convs with >= 8192 pixels run on conv_gemm_x6.hip (f32 products as six bf16 MFMAs on the exact three-term split): forward
+    (bias, residual, the qkv row permutation), data gradient, and -- through the direct kernels -- weight / bias gradients, against
+    F.conv2d on the CPU; ragged pixel counts; then the weights are changed in place and refreshed by repack_all()."""
+    monkeypatch.setattr(ops, "BF16X6", True)
+    x = fill.hash_tensor((B, cin, H, H), f"g6x{cin}{cout}", 1.0)
+    w = fill.hash_tensor((cout, cin, 1, 1), f"g6w{cin}{cout}", 1.0 / math.sqrt(cin))
+    b = fill.hash_tensor((cout,), f"g6b{cin}{cout}", 0.5)
+    r = fill.hash_tensor((B, cout, H, H), f"g6r{cin}{cout}", 1.0)
+    gy = fill.hash_tensor((B, cout, H, H), f"g6g{cin}{cout}", 1.0)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    y_ref = F.conv2d(xr, wr, br) + (r if with_res else 0)
+    (y_ref * gy).sum().backward()
+    xd = nhwc(x).requires_grad_(True)
+    wd, bd = torch.nn.Parameter(dev(w)), torch.nn.Parameter(dev(b))
+    monkeypatch.setattr(ops, "PROFILE", [])
+    y = ops.conv2d(xd, wd, bd, nhwc(r) if with_res else None, qkv=qkv)
+    assert [rec[0] for rec in ops.PROFILE].count("gemmx6") == 1 and wd._adm_packed.g6f is not None
+    yn = nchw(y)
+    if qkv:      # kernel rows are (head, {q,k,v}, c); the reference interleaves (head, c, {q,k,v}) (uncond_unet.py:205)
+        heads = cout // 192
+        yn = yn.reshape(B, heads, 3, 64, H, H).permute(0, 1, 3, 2, 4, 5).reshape(B, cout, H, H)
+    close(yn, y_ref)
+    if not qkv:
+        monkeypatch.setattr(ops, "PROFILE", [])
+        (y * nhwc(gy)).sum().backward()
+        assert [rec[0] for rec in ops.PROFILE].count("gemmx6") == (1 if cin % 128 == 0 else 0)       # the data gradient (N = Cin)
+        close(nchw(xd.grad), xr.grad)
+        close(wd.grad, wr.grad)
+        close(bd.grad, br.grad)
+    with torch.no_grad():
+        wd.data.mul_(0.5).add_(0.02)
+    ops.repack_all()
+    y2 = ops.conv2d(xd.detach(), wd, bd, nhwc(r) if with_res else None, qkv=qkv)
+    if not qkv:
+        close(nchw(y2), F.conv2d(x, wd.detach().cpu(), b) + (r if with_res else 0))
+    assert not torch.equal(y2, y.detach())
+
+
 def test_conv_x6_weights_follow_repack_all(ops, monkeypatch):
     """The fused optimiser rewrites parameters through raw pointers and refreshes every packed operand with one launch
     (ops.repack_all): the split-bf16 images must follow, bit for bit as adm_split3_bf16 would produce them."""

@@ -10,19 +10,20 @@ static void run(int B, int H, int Cin, int N, bool check) {
   std::vector<float> hx(nx), hw(nw);
   for (auto& v : hx) v = (rand() / (float)RAND_MAX) * 2 - 1;
   for (auto& v : hw) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.02f;
-  float *x, *w, *y, *y2, *ws = nullptr; void* w6;
+  float *x, *w, *y, *y2, *ws = nullptr, *res = nullptr; void* w6;
   long wsn = (long)adm_wino2d_x6_splitk(B, H, H, Cin, N) * ny;
   if (wsn < (long)ny * 2 || getenv("X6_NOSPLIT")) wsn = 0;
   hipMalloc(&x, nx * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, ny * 4); hipMalloc(&y2, ny * 4); hipMalloc(&w6, nw * 6);
   if (wsn) hipMalloc(&ws, wsn * 4);
+  if (getenv("X6_RES")) { hipMalloc(&res, ny * 4); hipMemset(res, 0, ny * 4); }
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
   adm_split3_bf16(w, w6, N, Cin, 0);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, 0);
+  for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, res, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, 0);
   hipDeviceSynchronize();
   const int reps = 20;
   hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, nullptr, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, 0);
+  for (int i = 0; i < reps; ++i) adm_conv_fwd_wino2d_x6(x, w6, nullptr, res, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, 0);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   double fl = 2.0 * B * H * H * (double)N * 9 * Cin;

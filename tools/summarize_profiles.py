@@ -24,6 +24,8 @@ def cls(n):
         return "wino2d_x6"
     if "wgrad_x6" in n:
         return "wgrad_x6"
+    if "gemm_x6" in n:
+        return "gemm_x6"
     if "igemm_wino2d" in n:
         return "wino2d"
     return ("wgrad_wino" if "wgrad_wino" in n else "wgrad" if "wgrad" in n else "wino" if "wino" in n else "igemm" if "igemm" in n else "attn" if "attn" in n else "gn" if "::gn_" in n
