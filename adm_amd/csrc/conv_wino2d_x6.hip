@@ -49,6 +49,7 @@ struct X6P {
   int Mt, N, H, W, Hh, Wh, Cin, ldx, ldy, ldr, wrows, tilesN, xbytes, wbytes, plane;   // plane = wrows * Cin (elements of one [term] image)
   int splitk, chunks_per_split; float* ws;
   int ybytes, rbytes;                  // > 0: y / res fit 32-bit byte offsets (branch-free buffer epilogue)
+  int up;                              // 1: x is [B][H/2][W/2][ldx] and the conv runs on its nearest x2 up-sampling (Conv2d(up=True))
 };
 
 typedef __attribute__((address_space(3))) void x6_lds_void;
@@ -124,15 +125,19 @@ __device__ __forceinline__ void x6_store(const f32x4 (&e)[4], unsigned short* la
 // (a stage = one (ey, chunk) pair).  Inside a (block, ey) group the MFMA accumulators run on (<= 24 matrix adds each); at its end
 // they are transformed and added to the output rows with f32 adds.
 constexpr int X6_KB = 4;
+// With the fused nearest x2 up-sampling the patch rows r1 and r2 are the SAME source row, so the pass ey = 2 (r2 - r1) is
+// identically zero and is skipped (three passes per block).
 struct X6Seq {
-  int k0, len, ey, cc;          // block start (chunk), block length, pass, chunk inside the block
-  __device__ __forceinline__ void init(int chunks) { k0 = 0; len = min(X6_KB, chunks); ey = 0; cc = 0; }
+  int k0, len, ey, cc, skip2;   // block start (chunk), block length, pass, chunk inside the block, skip pass 2
+  __device__ __forceinline__ void init(int chunks, int up) { k0 = 0; len = min(X6_KB, chunks); ey = 0; cc = 0; skip2 = up; }
   __device__ __forceinline__ int chunk() const { return k0 + cc; }
   __device__ __forceinline__ bool done() const { return len <= 0; }
   __device__ __forceinline__ void next(int chunks) {
     if (++cc == len) {
       cc = 0;
-      if (++ey == 4) { ey = 0; k0 += len; len = min(X6_KB, chunks - k0); }
+      ++ey;
+      if (skip2 && ey == 2) ++ey;
+      if (ey == 4) { ey = 0; k0 += len; len = min(X6_KB, chunks - k0); }
     }
   }
 };
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 
   const int c_begin = (p.splitk > 1) ? (int)blockIdx.y * p.chunks_per_split : 0;
   const int chunks = (p.splitk > 1) ? min(p.chunks_per_split, (p.Cin >> 4) - c_begin) : (p.Cin >> 4);     // 16-channel chunks (even)
-  const int S = 4 * chunks;                           // stages (an even number: Cin is a multiple of 32)
+  const int S = (p.up ? 3 : 4) * chunks;              // stages (an even number: Cin is a multiple of 32)
 
   if (producer) {
     // ================================================================ producer waves: A operand
@@ -175,7 +180,8 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
         const int xp = t % p.Wh;
         const int u = t / p.Wh;
         const int ty = u % p.Hh, b = u / p.Hh;
-        a_base = (unsigned)((((long)b * p.H + 2 * ty) * p.W + 2 * xp) * p.ldx + aq * 4) * 4u;
+        a_base = p.up ? (unsigned)((((long)b * p.Hh + ty) * p.Wh + xp) * p.ldx + aq * 4) * 4u        // source pixel (b, ty, xp)
+                      : (unsigned)((((long)b * p.H + 2 * ty) * p.W + 2 * xp) * p.ldx + aq * 4) * 4u;
         colmask = (xp > 0 ? 1u : 0u) | 6u | (2 * xp + 2 < p.W ? 8u : 0u);
         rowmask = (ty > 0 ? 1u : 0u) | 6u | (2 * ty + 2 < p.H ? 8u : 0u);
       }
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     // rows are 32 bytes; a 16-lane group of a fragment read covers 16 rows at one 16-byte half, i.e. only half of the banks, unless
     // the halves of rows 8-15 (mod 16) are swapped: physical half = logical half ^ ((row >> 3) & 1), for A and B alike
     unsigned short* la = As + pl * X6K + ((((aq >> 1) ^ (pl >> 3)) & 1) << 3) + (aq & 1) * 4;
-    X6Seq ld; ld.init(chunks);
+    X6Seq ld; ld.init(chunks, p.up);
     unsigned a_voff[2][4];
     int voff_ey = -1;
     auto set_rows = [&]() {     // pass ey combines input rows (iA, iB): 0: +r0 -r2   1: +r1 +r2   2: -r1 +r2   3: +r1 -r3; past the end: nothing
@@ -191,12 +197,15 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
       const int iA = (ey == 0) ? 0 : 1, iB = (ey == 3) ? 3 : 2;
       const bool live = !ld.done();
       const bool vA = ((rowmask >> iA) & 1u) && live, vB = ((rowmask >> iB) & 1u) && live;
-      const int offA = (iA - 1) * p.W * p.ldx * 4, offB = (iB - 1) * p.W * p.ldx * 4;
+      // up-sampled row 2ty - 1 + i reads source row ty + (i + 1) / 2 - 1 = ty - 1, ty, ty, ty + 1 (columns likewise)
+      const int offA = (p.up ? ((iA + 1) >> 1) - 1 : iA - 1) * (p.up ? p.Wh : p.W) * p.ldx * 4;
+      const int offB = (p.up ? ((iB + 1) >> 1) - 1 : iB - 1) * (p.up ? p.Wh : p.W) * p.ldx * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool cv = (colmask >> j) & 1u;
-        a_voff[0][j] = (vA && cv) ? a_base + (unsigned)(offA + (j - 1) * p.ldx * 4) : OOB;
-        a_voff[1][j] = (vB && cv) ? a_base + (unsigned)(offB + (j - 1) * p.ldx * 4) : OOB;
+        const int cj = (p.up ? ((j + 1) >> 1) - 1 : j - 1) * p.ldx * 4;
+        a_voff[0][j] = (vA && cv) ? a_base + (unsigned)(offA + cj) : OOB;
+        a_voff[1][j] = (vB && cv) ? a_base + (unsigned)(offB + cj) : OOB;
       }
       voff_ey = live ? ey : 4;
     };
@@ -236,11 +245,13 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     for (int t = 0; t < S; t += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        store(d, d & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(d);                                     // stages past the end read nothing (all offsets out of range)
-        __builtin_amdgcn_sched_barrier(0);
-        x6_barrier();
+        if (t + d < S) {                              // (uniform; S is even, a multiple of 4 without the up-sampling)
+          store(d, d & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(d);                                   // stages past the end read nothing (all offsets out of range)
+          __builtin_amdgcn_sched_barrier(0);
+          x6_barrier();
+        }
       }
     }
     return;
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     const int half = (lane ^ (row >> 3)) & 1;           // logical half stored at physical half (lane & 1)
     b_voff[i] = (n < p.wrows) ? (unsigned)((((long)pt * p.wrows + n) * 16 + half * 8) * 2) : OOB;
   }
-  X6Seq lb; lb.init(chunks);
+  X6Seq lb; lb.init(chunks, p.up);
   int ld_slot = 0;
   auto issue_b = [&]() {                              // weights of the next stage of the sequence -> next ring slot
     const int kb = ((lb.ey * (p.Cin >> 4) + c_begin + lb.chunk()) * 12 * p.wrows) << 5;   // (ey, chunk) block of twelve [ex][term] images of wrows x 32 bytes
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   const int b_foff = (wn * 32 + lr) * X6K + ((lh ^ (lr >> 3)) & 1) * 8;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  X6Seq cs; cs.init(chunks);
+  X6Seq cs; cs.init(chunks, p.up);
   int slot_b = 0;
   issue_b();
   issue_b();
@@ -443,19 +454,18 @@ extern "C" int adm_split3_bf16(const float* src, void* dst, int rows, int cols, 
 
 // Same contract as adm_conv_fwd_wino2d, with wq6 = adm_split3_bf16 of the adm_pack_weight_wino2d operand (16 planes of
 // wrows x Cin).
-extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,
-                                      long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
-                                      hipStream_t stream) {
+static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws, long ws_floats,
+                            int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int up, hipStream_t stream) {
   if (!x || !wq6 || !y || B <= 0 || H < 2 || W < 2 || (W & 1) || (H & 1)) return ADM_EINVAL;
   if ((Cin & 31) || (ldx & 3) || N <= 0 || wrows < N) return ADM_EINVAL;      // an even number of 16-channel chunks
   if (((uintptr_t)x | (uintptr_t)wq6) & 15) return ADM_EINVAL;
   X6P p;
   p.x = x; p.w = static_cast<const unsigned short*>(wq6); p.bias = bias; p.res = res; p.y = y;
   const long Mt = (long)B * (H / 2) * (W / 2);
-  const long xb = (long)B * H * W * ldx * 4, wb = 48L * wrows * Cin * 2;
+  const long xb = (long)B * H * W * ldx * 4 / (up ? 4 : 1), wb = 48L * wrows * Cin * 2;
   if (Mt >= (1L << 30) || xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;
   p.Mt = (int)Mt; p.N = N; p.H = H; p.W = W; p.Hh = H / 2; p.Wh = W / 2; p.Cin = Cin; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
-  p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin;
+  p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin; p.up = up ? 1 : 0;
   p.tilesN = adm_cdiv(N, X6N);
   p.splitk = 1; p.chunks_per_split = 0; p.ws = nullptr;
   const long yb = (long)B * H * W * ldy * 4, rb = res ? (long)B * H * W * ldr * 4 : 0;
@@ -481,6 +491,19 @@ extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const flo
   ADM_CHECK_LAUNCH();
   if (p.splitk > 1) return adm_splitk_reduce(ws, bias, res, y, Mt * 4, N, ldy, ldr, p.splitk, stream);
   return ADM_OK;
+}
+
+extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,
+                                      long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                                      hipStream_t stream) {
+  return wino2d_x6_launch(x, wq6, bias, res, y, ws, ws_floats, B, H, W, Cin, ldx, N, wrows, ldy, ldr, 0, stream);
+}
+
+// Conv2d(up=True): the same convolution on the nearest x2 up-sampling of x[B][H/2][W/2][ldx]; H x W is the OUTPUT grid (even)
+extern "C" int adm_conv_fwd_wino2d_x6_up(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,
+                                         long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                                         hipStream_t stream) {
+  return wino2d_x6_launch(x, wq6, bias, res, y, ws, ws_floats, B, H, W, Cin, ldx, N, wrows, ldy, ldr, 1, stream);
 }
 
 // Split count over the input channels for launches with fewer workgroups than CUs (one workgroup per CU here)

@@ -31,6 +31,7 @@ _SIGS = {
     "adm_wino2d_splitk": [I, I, I, I, I],
     "adm_wino2d_variant": [I],
     "adm_conv_fwd_wino2d_x6": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_fwd_wino2d_x6_up": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P],
     "adm_wino2d_x6_splitk": [I, I, I, I, I],
     "adm_split3_bf16": [P, P, I, I, P],
     "adm_gemm_x6": [P, P, P, P, P, L, I, I, I, I, I, I, P],

@@ -336,7 +336,8 @@ def _use_wino(B, Ho, Wo, ks, up, tile) -> bool:
 
 
 def _use_wino2d(B, Ho, Wo, ks, up, tile) -> bool:
-    return WINOGRAD2D and not up and (Ho & 1) == 0 and _use_wino(B, Ho, Wo, ks, up, tile)
+    # the fused nearest-x2 layers take the 2-D form on the split-bf16 kernel only (conv_wino2d_x6.hip skips their zero pass)
+    return WINOGRAD2D and (not up or BF16X6) and (Ho & 1) == 0 and _use_wino(B, Ho, Wo, ks, up, tile)
 
 
 def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None, wq2=None, wq6=None):
@@ -345,8 +346,8 @@ def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None,
     if wq2 is not None and wq6 is not None:
         sk = hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cin_p, n_p)
         ws = _new((sk * B * Ho * Wo * n_p,), x) if sk > 1 else None
-        call("adm_conv_fwd_wino2d_x6", ptr(x), ptr(wq6), ptr(bias), ptr(res), ptr(y), ptr(ws), 0 if ws is None else ws.numel(), B, Ho,
-             Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
+        call("adm_conv_fwd_wino2d_x6_up" if up else "adm_conv_fwd_wino2d_x6", ptr(x), ptr(wq6), ptr(bias), ptr(res), ptr(y), ptr(ws),
+             0 if ws is None else ws.numel(), B, Ho, Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
         return
     if wq2 is not None:
         sk = hip.lib().adm_wino2d_splitk(B, Ho, Wo, cin_p, n_p)

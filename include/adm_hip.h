@@ -105,6 +105,10 @@ int adm_conv_fwd_wino2d(const float* x, const float* wq, const float* bias, cons
 int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,
                            long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                            hipStream_t stream);
+/* ... on the nearest x2 up-sampling of x[B][H/2][W/2][ldx] (Conv2d(up=True), uncond_unet.py:105-108); H x W = the output grid */
+int adm_conv_fwd_wino2d_x6_up(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,
+                              long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                              hipStream_t stream);
 int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N);
 /* dst (48 * rows * cols bf16, layout [ey][cols/16][ex][term][rows][16]) <- exact split a = a0 + a1 + a2 of the sixteen Winograd
  * planes src[ey * 4 + ex][rows][cols] (f32) */

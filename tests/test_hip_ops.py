@@ -163,35 +163,48 @@ def test_conv_winograd_2d_forward_backward(ops, monkeypatch, request, B, cin, co
         assert float((y.detach() - yd).abs().max()) <= 2e-5 * float(yd.abs().max())
 
 
+@pytest.mark.parametrize("up", [False, True])
 @pytest.mark.parametrize("B,cin,cout,H,W", [(3, 32, 32, 8, 8), (2, 64, 96, 6, 10), (1, 3, 64, 16, 16), (4, 192, 192, 16, 16), (1, 32, 32, 2, 2),
-                                            (2, 384, 384, 8, 8), (8, 64, 96, 32, 32), (130, 32, 64, 2, 4)])
-def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W):
+                                            (2, 384, 384, 8, 8), (8, 64, 96, 32, 32), (130, 32, 64, 2, 4), (2, 96, 64, 3, 5)])
+def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W, up):
     """The default 3x3 path (conv_wino2d_x6.hip): the 2-D Winograd convolution with every f32 product carried by six bf16 MFMAs on
-    the exact three-term split of both operands.  Same parity bar as the f32-MFMA kernels, against F.conv2d."""
+    the exact three-term split of both operands -- forward, data gradient and (conv_wgrad_x6.hip, power-of-two sizes) weight gradient,
+    plain and with the fused nearest x2 up-sampling of Conv2d(up=True) (H x W is then the INPUT size).  Same parity bar as the
+    f32-MFMA kernels, against F.conv2d on the CPU."""
+    if not up and (H % 2 or W % 2):
+        pytest.skip("odd sizes take the 1-D kernels")
     monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     monkeypatch.setattr(ops, "WINOGRAD", True)
     monkeypatch.setattr(ops, "WINOGRAD2D", True)
     monkeypatch.setattr(ops, "BF16X6", True)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
     x = fill.hash_tensor((B, cin, H, W), f"x6x{cin}{cout}{H}", 1.0)
     w = fill.hash_tensor((cout, cin, 3, 3), f"x6w{cin}{cout}", 1.0 / math.sqrt(cin * 9))
     b = fill.hash_tensor((cout,), f"x6b{cin}{cout}", 0.5)
-    r = fill.hash_tensor((B, cout, H, W), f"x6r{cin}{cout}{H}", 1.0)
-    gy = fill.hash_tensor((B, cout, H, W), f"x6g{cin}{cout}{H}", 1.0)
+    r = fill.hash_tensor((B, cout, Ho, Wo), f"x6r{cin}{cout}{H}", 1.0)
+    gy = fill.hash_tensor((B, cout, Ho, Wo), f"x6g{cin}{cout}{H}", 1.0)
     xr, wr, br, rr = [t.clone().requires_grad_(True) for t in (x, w, b, r)]
-    y_ref = F.conv2d(xr, wr, br, padding=1) + rr
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    y_ref = F.conv2d(xin, wr, br, padding=1) + rr
     (y_ref * gy).sum().backward()
     cip, cop = ops.ceil32(cin), ops.ceil32(cout)
     xd = nhwc(pad_c(x, cip)).requires_grad_(True)
     wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     rd = nhwc(pad_c(r, cop)).requires_grad_(True)
     monkeypatch.setattr(ops, "PROFILE", [])
-    y = ops.conv2d(xd, wd, bd, rd)
+    y = ops.conv2d(xd, wd, bd, rd, up=up)
     assert wd._adm_packed.w2f6 is not None, "the split-bf16 path was not taken"
     close(nchw(y)[:, :cout], y_ref)
     (y * nhwc(pad_c(gy, cop))).sum().backward()
-    assert [rec[0] for rec in ops.PROFILE].count("wino2x6") == 2        # forward + data gradient
+    kinds = [rec[0] for rec in ops.PROFILE]
+    assert kinds.count("wino2x6") == 2                                   # forward + data gradient
+    pow2 = lambda v: v & (v - 1) == 0
+    if not up and pow2(H) and pow2(W):
+        assert kinds.count("wgrad_wino2x6") == 1
     close(nchw(xd.grad)[:, :cin], xr.grad)
     close(wd.grad, wr.grad)
+    close(bd.grad, br.grad)
+    close(nchw(rd.grad)[:, :cout], rr.grad)
 
 
 @pytest.mark.parametrize("B,cin,cout,H,qkv,with_res", [(8, 384, 1152, 32, True, False), (8, 384, 384, 32, False, True), (9, 192, 384, 31, False, False),
