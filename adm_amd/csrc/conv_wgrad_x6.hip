@@ -32,6 +32,7 @@ struct WxP {
   const float* x; const float* dy; float* dwp; float* dbias;
   int Pp, H, W, lw, Cin, ldx, Cout, lddy, tilesN, chunk, atomic, xbytes, dybytes;     // Pp = 2x2 tiles in all; chunk = tiles per split
   long split_stride, bias_stride;      // > 0: deterministic mode, partials of split z at dwp + z * split_stride (plain stores)
+  int up;                              // 1: x is [B][H/2][W/2][ldx], the conv ran on its nearest x2 up-sampling (Conv2d(up=True))
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
   const int pbeg = blockIdx.z * p.chunk;
   const int pend = min(p.Pp, pbeg + p.chunk);
   if (pbeg >= pend) return;                        // (whole workgroup)
-  const int KT = (pend - pbeg + XK - 1) / XK;      // stages
+  int KT = (pend - pbeg + XK - 1) / XK;            // stages
+  // fused nearest x2: patch rows r1 and r2 are the same source row, so the X side of the pass ey = 2 (r2 - r1) is identically zero;
+  // these workgroups only write their zeros (plain-store modes) -- no stages, no barriers, for either role
+  if (p.up && ey == 2) KT = 0;
   constexpr unsigned OOB = 0x80000000u;
 
   if (producer) {
@@ -127,13 +131,18 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
       t1[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y1, 0, 0));
       t1[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y1 != OOB ? y1 + ystep : OOB), 0, 0));
       const bool vA = pv && b_col != OOB && (iA != 0 || ty > 0), vB = pv && b_col != OOB && (iB != 3 || ty < Hh - 1);
-      const unsigned xa = pix * xstep + b_col + (unsigned)((iA - 1) * p.W - 1) * xstep;      // row iA, column 2xp - 1 (may wrap: masked)
-      const unsigned xb = pix * xstep + b_col + (unsigned)((iB - 1) * p.W - 1) * xstep;
+      // up-sampled: the tile's source pixel is pixel `pr` of the half-resolution image; up-sampled row 2ty - 1 + i reads source row
+      // ty + (i + 1) / 2 - 1 (columns likewise)
+      const unsigned xa = p.up ? ((unsigned)pr + (unsigned)((((iA + 1) >> 1) - 1) * Wh)) * xstep + b_col
+                               : pix * xstep + b_col + (unsigned)((iA - 1) * p.W - 1) * xstep;      // row iA, column 2xp - 1 (may wrap: masked)
+      const unsigned xb = p.up ? ((unsigned)pr + (unsigned)((((iB + 1) >> 1) - 1) * Wh)) * xstep + b_col
+                               : pix * xstep + b_col + (unsigned)((iB - 1) * p.W - 1) * xstep;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool cv = (j != 0 || xp > 0) && (j != 3 || xp < Wh - 1);
-        u0[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vA && cv) ? xa + j * xstep : OOB), 0, 0));
-        u1[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vB && cv) ? xb + j * xstep : OOB), 0, 0));
+        const unsigned cj = p.up ? (unsigned)(((j + 1) >> 1) - 1) * xstep : (unsigned)j * xstep;
+        u0[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vA && cv) ? xa + cj : OOB), 0, 0));
+        u1[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vB && cv) ? xb + cj : OOB), 0, 0));
       }
     };
     // the bias gradient = sum of every dY pixel = the ex = 1 component (e0 + e1 along x) of the ey = 1 workgroups (r0 + r1 along y)
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
 }
 
 int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                  int lddy, int splits, bool det, bool plan_only, hipStream_t stream) {
+                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream) {
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
   if (B <= 0 || H < 2 || W < 2) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
@@ -276,8 +285,9 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   WxP p;
   p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
   const long P = (long)B * H * W;
-  const long xb = P * ldx * 4, db = P * lddy * 4;
+  const long xb = (up ? P / 4 : P) * ldx * 4, db = P * lddy * 4;
   if (xb >= (1L << 31) - (1L << 22) || db >= (1L << 31) - (1L << 22)) return ADM_EINVAL;   // 32-bit offsets
+  p.up = up ? 1 : 0;
   p.Pp = (int)(P / 4); p.H = H; p.W = W; p.lw = lw; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, XT);
@@ -324,14 +334,19 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
 // dbias += column sums of dy; splits = 0 picks the split count; H and W powers of two >= 2.
 extern "C" int adm_conv_wgrad_x6(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx,
                                  int Cout, int lddy, int splits, hipStream_t stream) {
-  return wgrad_x6_impl(x, dy, dwp2, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, false, false, stream);
+  return wgrad_x6_impl(x, dy, dwp2, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, false, false, 0, stream);
+}
+// Weight gradient of Conv2d(up=True): x is the conv's HALF-resolution input [B][H/2][W/2][ldx]; H x W is dy's grid
+extern "C" int adm_conv_wgrad_x6_up(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx,
+                                    int Cout, int lddy, int splits, hipStream_t stream) {
+  return wgrad_x6_impl(x, dy, dwp2, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, false, false, 1, stream);
 }
 // Deterministic workspace mode: split z writes its partial planes to ws[z][Cout][12][Cin] and its bias partial to bws[z][Cout]
 // (plain stores); splits must be adm_conv_wgrad_x6_plan(...)
 extern "C" int adm_conv_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx,
-                                    int Cout, int lddy, int splits, hipStream_t stream) {
-  return wgrad_x6_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, true, false, stream);
+                                    int Cout, int lddy, int splits, int up, hipStream_t stream) {
+  return wgrad_x6_impl(x, dy, ws, bws, B, H, W, Cin, ldx, Cout, lddy, splits, true, false, up, stream);
 }
 extern "C" int adm_conv_wgrad_x6_plan(int B, int H, int W, int Cin, int Cout) {
-  return wgrad_x6_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, 0, false, true, nullptr);
+  return wgrad_x6_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, 0, false, true, 0, nullptr);
 }

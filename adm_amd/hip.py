@@ -37,7 +37,8 @@ _SIGS = {
     "adm_gemm_x6": [P, P, P, P, P, L, I, I, I, I, I, I, P],
     "adm_split3_rows": [P, P, I, I, I, P],
     "adm_conv_wgrad_x6": [P, P, P, P, I, I, I, I, I, I, I, I, P],
-    "adm_conv_wgrad_x6_ws": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_x6_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_x6_ws": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_x6_plan": [I, I, I, I, I],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino": [P, P, P, P, I, I, I, I, I, I, I, I, P],

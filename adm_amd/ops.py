@@ -447,7 +447,7 @@ class _Conv(torch.autograd.Function):
                         dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
                 wino_w = (not bf16 and _use_wino(B, Ho, Wo, ks, up, -1) and not qkv and pow2(Ho) and pow2(Wo))
-                wino2_w = wino_w and WINOGRAD2D and not up and Ho >= 2          # 2-D F(3x3, 2x2): 12 x-folded planes per cout
+                wino2_w = wino_w and WINOGRAD2D and (not up or BF16X6) and Ho >= 2   # 2-D F(3x3, 2x2): 12 x-folded planes per cout
                 wmode = 2 if wino2_w else int(wino_w)
                 planes = 12 if wino2_w else ks * ks
                 det = DETERMINISTIC and not bf16
@@ -468,12 +468,13 @@ class _Conv(torch.autograd.Function):
                     if bf16:
                         call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
                     elif det and x6_w:
-                        call("adm_conv_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, splits)
+                        call("adm_conv_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, splits, int(up))
                     elif det:
                         call("adm_conv_wgrad_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, ks, int(up),
                              splits, wmode)
                     elif x6_w:
-                        call("adm_conv_wgrad_x6", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, 0)
+                        call("adm_conv_wgrad_x6_up" if up else "adm_conv_wgrad_x6", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip,
+                             cip, cop, cop, 0)
                     elif wino2_w:
                         call("adm_conv_wgrad_wino2d", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, 0)
                     elif wino_w:

@@ -126,8 +126,11 @@ int adm_split3_rows(const float* src, void* dst, int rows, int cols, int ld, hip
  * Replaces the autograd weight gradient of Conv2d.forward (/root/reference/unet/uncond_unet.py:98-110). */
 int adm_conv_wgrad_x6(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
                       int lddy, int splits, hipStream_t stream);
-int adm_conv_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
+/* _up: weight gradient of Conv2d(up=True): x is the conv's half-resolution input [B][H/2][W/2][ldx], H x W is dy's grid */
+int adm_conv_wgrad_x6_up(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
                          int lddy, int splits, hipStream_t stream);
+int adm_conv_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
+                         int lddy, int splits, int up, hipStream_t stream);
 int adm_conv_wgrad_x6_plan(int B, int H, int W, int Cin, int Cout);
 /* kernel variant of adm_conv_fwd_wino2d: -1 (default) chosen per launch, 1 wave-specialised (producer / consumer waves), 0 symmetric;
  * returns the old value */

@@ -199,7 +199,7 @@ def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W, up):
     kinds = [rec[0] for rec in ops.PROFILE]
     assert kinds.count("wino2x6") == 2                                   # forward + data gradient
     pow2 = lambda v: v & (v - 1) == 0
-    if not up and pow2(H) and pow2(W):
+    if pow2(Ho) and pow2(Wo):
         assert kinds.count("wgrad_wino2x6") == 1
     close(nchw(xd.grad)[:, :cin], xr.grad)
     close(wd.grad, wr.grad)
@@ -327,11 +327,11 @@ def test_conv_wgrad_winograd_op_level(ops, monkeypatch, B, cin, cout, H, W, up, 
     kinds = [r[0] for r in ops.PROFILE]
     # even-height, non-upsampled shapes take the 2-D F(3x3,2x2) form -- by default with the f32 products on the bf16 MFMA
     # (conv_wgrad_x6.hip) --, the others the 1-D F(3,2) form
-    two_d = not up and H >= 2
+    two_d = Ho >= 2                                            # (all the shapes here are powers of two)
     assert kinds.count("wgrad_wino2x6" if two_d else "wgrad_wino") == 1 and "wgrad" not in kinds, kinds
     close(wd.grad, wr.grad)
     close(bd.grad, br.grad)
-    if two_d:                                                  # ... the f32-MFMA 2-D form (ADM_BF16X6=0) on the same problem
+    if two_d and not up:                                       # ... the f32-MFMA 2-D form (ADM_BF16X6=0) on the same problem
         monkeypatch.setattr(ops, "BF16X6", False)
         wd1, bd1 = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
         monkeypatch.setattr(ops, "PROFILE", [])
