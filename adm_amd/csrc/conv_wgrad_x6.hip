@@ -86,6 +86,10 @@ __device__ __forceinline__ void lds_barrier() {    // waits for this wave's LDS 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// MODE 0: the 3x3 Winograd form above.  MODE 1: the weight gradient of a 1x1 conv, dW[co][ci] = sum_pixels dY[p][co] X[p][ci]: the same
+// images, reads and MFMAs with the four `ex` planes of a stage holding four consecutive 16-pixel chunks (64 pixels per stage, no
+// transforms, gridDim.y = 1); the epilogue adds the four accumulators.
+template <int MODE>
 __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smx[];
   unsigned short* As = smx;                        // [2][X_IMG]  dY side: rows = tiles, columns = couts
@@ -99,10 +103,11 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
   const int pbeg = blockIdx.z * p.chunk;
   const int pend = min(p.Pp, pbeg + p.chunk);
   if (pbeg >= pend) return;                        // (whole workgroup)
-  int KT = (pend - pbeg + XK - 1) / XK;            // stages
+  constexpr int STEP = MODE == 1 ? 4 * XK : XK;    // reduction items (tiles / pixels) per stage
+  int KT = (pend - pbeg + STEP - 1) / STEP;        // stages
   // fused nearest x2: patch rows r1 and r2 are the same source row, so the X side of the pass ey = 2 (r2 - r1) is identically zero;
   // these workgroups only write their zeros (plain-store modes) -- no stages, no barriers, for either role
-  if (p.up && ey == 2) KT = 0;
+  if (MODE == 0 && p.up && ey == 2) KT = 0;
   constexpr unsigned OOB = 0x80000000u;
 
   if (producer) {
@@ -119,6 +124,16 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
     constexpr int D = 3;                           // stages in flight
     f32x4 t0[D][2], t1[D][2], u0[D][4], u1[D][4];
     auto issue = [&](int d, int s) {               // loads of stage s -> register set d (stages past the end read nothing)
+      if (MODE == 1) {                             // chunk xi of the stage: pixel pbeg + 64 s + 16 xi + tl, one quad of dY and of X
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+          const int px = pbeg + s * STEP + xi * XK + tl;
+          const bool pv = px < pend && s < KT;
+          u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)((pv && a_col != OOB) ? (unsigned)px * ystep + a_col : OOB), 0, 0));
+          u1[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((pv && b_col != OOB) ? (unsigned)px * xstep + b_col : OOB), 0, 0));
+        }
+        return;
+      }
       const int pr = pbeg + s * XK + tl;
       const bool pv = pr < pend && s < KT;
       const int xp = pr & (Wh - 1), ty = (pr >> lwh) & (Hh - 1);
@@ -146,11 +161,17 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
       }
     };
     // the bias gradient = sum of every dY pixel = the ex = 1 component (e0 + e1 along x) of the ey = 1 workgroups (r0 + r1 along y)
-    const bool do_bias = p.dbias != nullptr && tn == 0 && ey == 1;
+    const bool do_bias = p.dbias != nullptr && tn == 0 && ey == (MODE == 1 ? 0 : 1);
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     unsigned short* la = As + tl * XROW + quad * 4;
     unsigned short* lb = Bs + tl * XROW + quad * 4;
     auto store = [&](int d, int slot) {            // y combination, x transforms, split, into slot
+      if (MODE == 1) {
+        if (do_bias) bsum += (u0[d][0] + u0[d][1]) + (u0[d][2] + u0[d][3]);
+        store_planes(u0[d], la + slot * X_IMG);
+        store_planes(u1[d], lb + slot * X_IMG);
+        return;
+      }
       f32x4 e[2], dd[4];
       if (ey <= 1) { e[0] = t0[d][0] + t1[d][0]; e[1] = t0[d][1] + t1[d][1]; }     // the unused row was read as zeros
       else { e[0] = sub4x(t0[d][0], t1[d][0]); e[1] = sub4x(t0[d][1], t1[d][1]); }
@@ -248,7 +269,7 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
       for (int xi = 0; xi < 4; ++xi) tot[xi] += acc[xi];
     }
   }
-  if (p.dbias != nullptr && tn == 0 && ey == 1) {  // the producers' bias reduction uses two more barriers
+  if (p.dbias != nullptr && tn == 0 && ey == (MODE == 1 ? 0 : 1)) {  // the producers' bias reduction uses two more barriers
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
   }
@@ -262,6 +283,12 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
   for (int r = 0; r < 16; ++r) {
     const int co = cb + (r & 3) + 8 * (r >> 2);
     if (co >= p.Cout) continue;
+    if (MODE == 1) {
+      const float w = (tot[0][r] + tot[1][r]) + (tot[2][r] + tot[3][r]);
+      float* dst1 = p.dwp + (long)blockIdx.z * p.split_stride + (long)co * p.Cin + ci;
+      if (p.atomic) atomicAdd(dst1, w); else dst1[0] = w;
+      continue;
+    }
     const float h = 0.5f * (tot[1][r] + tot[2][r]);
     const float w0 = tot[0][r] + h, w1 = 0.5f * (tot[1][r] - tot[2][r]), w2 = h + tot[3][r];
     float* dst = p.dwp + (long)blockIdx.z * p.split_stride + ((long)co * 12 + ey * 3) * p.Cin + ci;
@@ -274,7 +301,15 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
 }
 
 int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream) {
+                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int mode = 0);
+
+// MODE 1 host side: P pixels, no geometry
+int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
+                      bool det, bool plan_only, hipStream_t stream);
+
+int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
+                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int mode) {
+  (void)mode;
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
   if (B <= 0 || H < 2 || W < 2) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
@@ -317,13 +352,61 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   dim3 grid(adm_cdiv(Cout, XT) * p.tilesN, 4, splits);
-  hipLaunchKernelGGL(wgrad_x6_kernel, grid, dim3(512), smem, stream, p);
+  hipLaunchKernelGGL(wgrad_x6_kernel<0>, grid, dim3(512), smem, stream, p);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
+                      bool det, bool plan_only, hipStream_t stream) {
+  if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
+  if (P <= 0 || (Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
+  if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
+  const long xb = P * ldx * 4, db = P * lddy * 4;
+  if (P >= (1L << 30) || xb >= (1L << 31) || db >= (1L << 31)) return ADM_EINVAL;
+  WxP p;
+  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
+  p.Pp = (int)P; p.H = 0; p.W = 0; p.lw = 0; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.up = 0;
+  p.xbytes = (int)xb; p.dybytes = (int)db;
+  p.tilesN = adm_cdiv(Cin, XT);
+  const long tiles = (long)adm_cdiv(Cout, XT) * p.tilesN;
+  constexpr int STEP = 4 * XK;
+  if (splits <= 0) {        // whole rounds of 256 workgroups (one per CU); >= 6 stages (384 pixels) per split
+    const long slots = 256;
+    const int maxs = (int)std::min<long>((P + 6 * STEP - 1) / (6 * STEP), 128);
+    double best = -1.0;
+    splits = 1;
+    for (int sN = 1; sN <= maxs; ++sN) {
+      const long wgs = tiles * sN;
+      const long rounds = (wgs + slots - 1) / slots;
+      const double fill = (double)wgs / (double)(rounds * slots) - 0.001 * sN;
+      if (fill > best + 1e-9) { best = fill; splits = sN; }
+    }
+  }
+  int chunk = (int)(((P + splits - 1) / splits + STEP - 1) / STEP * STEP);
+  splits = (int)((P + chunk - 1) / chunk);
+  if (plan_only) return splits;
+  p.chunk = chunk;
+  p.split_stride = det ? (long)Cout * Cin : 0;
+  p.bias_stride = det ? Cout : 0;
+  p.atomic = splits > 1 && !det;
+  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
+  constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+        hipSuccess)
+      return ADM_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(adm_cdiv(Cout, XT) * p.tilesN, 1, splits);
+  hipLaunchKernelGGL(wgrad_x6_kernel<1>, grid, dim3(512), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -349,4 +432,19 @@ extern "C" int adm_conv_wgrad_x6_ws(const float* x, const float* dy, float* ws, 
 }
 extern "C" int adm_conv_wgrad_x6_plan(int B, int H, int W, int Cin, int Cout) {
   return wgrad_x6_impl(nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cin, Cout, Cout, 0, false, true, 0, nullptr);
+}
+
+// Weight gradient of a 1x1 conv / pixel-wise linear map on the same kernel (MODE 1): dwp[Cout][Cin] (+)= sum over P pixels of
+// dy[p][co] x[p][ci], dbias += column sums of dy.  splits = 0: chosen by the launcher.  _ws: deterministic mode (split z stores its
+// partial at ws[z][Cout][Cin] / bws[z][Cout]); splits must be adm_gemm_wgrad_x6_plan(...).
+extern "C" int adm_gemm_wgrad_x6(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy,
+                                 int splits, hipStream_t stream) {
+  return wgrad_x6_1x1_impl(x, dy, dwp, dbias, P, Cin, ldx, Cout, lddy, splits, false, false, stream);
+}
+extern "C" int adm_gemm_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, long P, int Cin, int ldx, int Cout, int lddy,
+                                    int splits, hipStream_t stream) {
+  return wgrad_x6_1x1_impl(x, dy, ws, bws, P, Cin, ldx, Cout, lddy, splits, true, false, stream);
+}
+extern "C" int adm_gemm_wgrad_x6_plan(long P, int Cin, int Cout) {
+  return wgrad_x6_1x1_impl(nullptr, nullptr, nullptr, nullptr, P, Cin, Cin, Cout, Cout, 0, false, true, nullptr);
 }

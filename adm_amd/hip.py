@@ -40,6 +40,9 @@ _SIGS = {
     "adm_conv_wgrad_x6_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_x6_ws": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_x6_plan": [I, I, I, I, I],
+    "adm_gemm_wgrad_x6": [P, P, P, P, L, I, I, I, I, I, P],
+    "adm_gemm_wgrad_x6_ws": [P, P, P, P, L, I, I, I, I, I, P],
+    "adm_gemm_wgrad_x6_plan": [L, I, I],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_wino_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],
@@ -150,7 +153,7 @@ def ptr(t) -> c_void_p:
 
 
 NO_STREAM = ("adm_version", "adm_conv_splitk", "adm_gn_splits", "adm_aug_workspace_floats", "adm_conv_wgrad_plan",
-             "adm_sumsq_blocks", "adm_lnc_blocks", "adm_bn_blocks", "adm_linattn_ws_floats", "adm_wino2d_splitk", "adm_wino2d_x6_splitk", "adm_wino2d_variant", "adm_gn_fused", "adm_conv_wgrad_x6_plan")      # host-side queries: no stream argument, called as lib().name(...)
+             "adm_sumsq_blocks", "adm_lnc_blocks", "adm_bn_blocks", "adm_linattn_ws_floats", "adm_wino2d_splitk", "adm_wino2d_x6_splitk", "adm_wino2d_variant", "adm_gn_fused", "adm_conv_wgrad_x6_plan", "adm_gemm_wgrad_x6_plan")      # host-side queries: no stream argument, called as lib().name(...)
 
 
 def call(name: str, *args):

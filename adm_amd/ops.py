@@ -139,6 +139,10 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
 
 
 GEMM_X6_MIN_M = 8192
+# The 1x1 WEIGHT gradient on the split-bf16 kernel (conv_wgrad_x6.hip MODE 1) is correct but not faster than the f32 direct kernel
+# (measured 65-103 vs 47-111 TFLOP/s per shape, step 777 vs 802 images/s: 32x32 wave tiles need two transposed fragment reads per
+# MFMA): kept behind a switch, off.
+GEMM_WGRAD_X6 = os.environ.get("ADM_GEMM_WGRAD_X6", "0") == "1"
 
 
 def _use_gemm_x6(M: int, ks: int, up, n_p: int, k_p: int) -> bool:
@@ -452,9 +456,11 @@ class _Conv(torch.autograd.Function):
                 planes = 12 if wino2_w else ks * ks
                 det = DETERMINISTIC and not bf16
                 x6_w = wino2_w and BF16X6          # f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip)
+                g6_w = GEMM_WGRAD_X6 and BF16X6 and not bf16 and ks == 1 and not up and B * Ho * Wo >= GEMM_X6_MIN_M      # ... 1x1 convs (its MODE 1)
                 splits = 1
                 if det:        # splits store partial tiles to a workspace; the unpack launch sums them in a fixed order
                     splits = (hip.lib().adm_conv_wgrad_x6_plan(B, Ho, Wo, cip, cop) if x6_w else
+                              hip.lib().adm_gemm_wgrad_x6_plan(B * Ho * Wo, cip, cop) if g6_w else
                               hip.lib().adm_conv_wgrad_plan(B, Ho, Wo, cip, cop, ks, int(up), wmode))
                     if splits < 1:
                         raise RuntimeError(f"adm_conv_wgrad_plan failed with code {splits}")
@@ -462,11 +468,15 @@ class _Conv(torch.autograd.Function):
                     bws = _new((splits, cop), dy) if dbp is not None else None
                 else:
                     dwp = _new((cop, planes * cip), dy)
-                kind = "wgrad_wino2x6" if x6_w else "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
+                kind = "wgrad_wino2x6" if x6_w else "wgrad_gemmx6" if g6_w else "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
                 with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"{kind.replace('_', '-')} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16:
                         call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+                    elif det and g6_w:
+                        call("adm_gemm_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B * Ho * Wo, cip, cip, cop, cop, splits)
+                    elif g6_w:
+                        call("adm_gemm_wgrad_x6", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B * Ho * Wo, cip, cip, cop, cop, 0)
                     elif det and x6_w:
                         call("adm_conv_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, splits, int(up))
                     elif det:

@@ -132,6 +132,13 @@ int adm_conv_wgrad_x6_up(const float* x, const float* dy, float* dwp2, float* db
 int adm_conv_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, int B, int H, int W, int Cin, int ldx, int Cout,
                          int lddy, int splits, int up, hipStream_t stream);
 int adm_conv_wgrad_x6_plan(int B, int H, int W, int Cin, int Cout);
+/* Weight gradient of a 1x1 conv on the same kernel (conv_wgrad_x6.hip, MODE 1): dwp[Cout][Cin] (+)= sum over P pixels of
+ * dy[p][co] x[p][ci] (-> adm_unpack_wgrad with ks = 1), dbias += column sums of dy; _ws / _plan as for adm_conv_wgrad_x6. */
+int adm_gemm_wgrad_x6(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy,
+                      int splits, hipStream_t stream);
+int adm_gemm_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, long P, int Cin, int ldx, int Cout, int lddy,
+                         int splits, hipStream_t stream);
+int adm_gemm_wgrad_x6_plan(long P, int Cin, int Cout);
 /* kernel variant of adm_conv_fwd_wino2d: -1 (default) chosen per launch, 1 wave-specialised (producer / consumer waves), 0 symmetric;
  * returns the old value */
 int adm_wino2d_variant(int ws);
