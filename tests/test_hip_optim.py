@@ -124,10 +124,11 @@ def test_table_repack_equals_per_layer_pack():
     gpu = torch.device("cuda:0")
     m = _model(gpu)
     old_min, ops.WINO_MIN_M = ops.WINO_MIN_M, 1    # batch 2: force the 3x3 layers through Winograd so their operands exist
-    try:
+    old_x6, ops.BF16X6 = ops.BF16X6, False         # f32-MFMA kernels: 1-D operands for the up-sampling layers, 2-D for the others
+    try:                                           # (the split-bf16 images: tests/test_hip_ops.py::test_conv_x6_weights_follow_repack_all)
         _loss(m, gpu).backward()                   # populates the packed-operand cache for every layer
     finally:
-        ops.WINO_MIN_M = old_min
+        ops.WINO_MIN_M, ops.BF16X6 = old_min, old_x6
     ents = [(w(), ks, qkv) for w, _b, ks, qkv in ops._pack_registry.values() if w() is not None and w().is_cuda]
     mine = [(w, ks, qkv) for (w, ks, qkv) in ents if any(w is p for p in m.parameters())]
     assert len(mine) > 50
@@ -148,5 +149,10 @@ def test_table_repack_equals_per_layer_pack():
             call("adm_pack_weight_wino", ptr(w.detach()), ptr(wf), ptr(wb), co, ci, cop, cip)
             assert torch.equal(wf, ent.wf) and torch.equal(wb, ent.wb), tuple(w.shape)
             kinds.add("wino")
+        if ent.w2f is not None:                    # ... and the 2-D Winograd planes
+            w2f, w2b = torch.empty_like(ent.w2f), torch.empty_like(ent.w2b)
+            call("adm_pack_weight_wino2d", ptr(w.detach()), ptr(w2f), ptr(w2b), co, ci, cop, cip)
+            assert torch.equal(w2f, ent.w2f) and torch.equal(w2b, ent.w2b), tuple(w.shape)
+            kinds.add("wino2d")
         kinds.add((ks, bool(qkv), cop != co, cip != ci))
-    assert {(3, False, False, True), (3, False, True, False), (1, True, False, False), (1, False, False, False), "wino"} <= kinds
+    assert {(3, False, False, True), (3, False, True, False), (1, True, False, False), (1, False, False, False), "wino", "wino2d"} <= kinds
