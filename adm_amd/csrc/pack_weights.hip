@@ -103,12 +103,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 }
 
 // One launch for ALL layers of a model.  table[e] = {src, dst_fwd, dst_bwd, Co, Ci, taps, Co_pad, Ci_pad, qkv, tile_begin,
-// dst_wino_fwd, dst_wino_bwd, dst_wino2d_fwd, dst_wino2d_bwd, dst_x6_fwd, dst_x6_bwd} (int64 each; tile_begin = exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) over the rows, in
+// dst_wino_fwd, dst_wino_bwd, dst_wino2d_fwd, dst_wino2d_bwd, dst_x6_fwd, dst_x6_bwd, dst_gemm_x6_fwd, dst_gemm_x6_bwd} (int64 each; tile_begin = exclusive prefix sum of (Co_pad/32)*(Ci_pad/32) over the rows, in
 // row order; the two Winograd destinations are 0 for layers that do not use conv_wino.hip).  One workgroup per 32
 // (out-channel) x 32 (in-channel) tile of one layer: the tile's taps-interleaved source runs (32*taps contiguous floats per
 // out-channel) go through LDS once and leave as 128-byte row segments of every operand layout, so reads and writes are
 // coalesced (the previous element-per-thread gather ran at 0.7 TB/s and cost 3.8 ms per optimiser step).
-constexpr int PT_COLS = 16;
+constexpr int PT_COLS = 18;
 __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict__ table, int n_entries) {
   __shared__ float tile[32][32 * 9 + 1];
   // layer of this tile: last row whose tile_begin <= blockIdx.x
@@ -137,15 +137,37 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
     tile[r][c] = v;
   }
   __syncthreads();
+  // 1x1 layers on conv_gemm_x6.hip: the exact three-term bf16 split of both operands, [k/16][term][rows][16] (columns 16, 17)
+  unsigned short* __restrict__ g6f = reinterpret_cast<unsigned short*>(t[16]);
+  unsigned short* __restrict__ g6b = reinterpret_cast<unsigned short*>(t[17]);
+  auto split_store = [](unsigned short* d6, long term6, float v) {
+    const unsigned b0 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(b0 & 0xFFFF0000u);
+    const unsigned b1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
+    d6[0] = (unsigned short)(b0 >> 16);
+    d6[term6] = (unsigned short)(b1 >> 16);
+    d6[2 * term6] = (unsigned short)(__float_as_uint(r2) >> 16);
+  };
   for (int e = threadIdx.x; e < n; e += 256) {     // forward operand [Co_pad][taps][Ci_pad]: ci fastest
     const int ci_l = e & 31, rest = e >> 5;
     const int tap = rest % taps, co_l = rest / taps;
-    fwd[((long)(co0 + co_l) * taps + tap) * Ci_pad + ci0 + ci_l] = tile[co_l][ci_l * taps + tap];
+    const float v = tile[co_l][ci_l * taps + tap];
+    fwd[((long)(co0 + co_l) * taps + tap) * Ci_pad + ci0 + ci_l] = v;
+    if (g6f && taps == 1) {
+      const int k = ci0 + ci_l;
+      split_store(g6f + ((((long)(k >> 4) * 3) * Co_pad + co0 + co_l) << 4) + (k & 15), (long)Co_pad << 4, v);
+    }
   }
   for (int e = threadIdx.x; e < n; e += 256) {     // data-gradient operand [Ci_pad][taps flipped][Co_pad]: co fastest
     const int co_l = e & 31, rest = e >> 5;
     const int tapf = rest % taps, ci_l = rest / taps;
-    bwd[((long)(ci0 + ci_l) * taps + tapf) * Co_pad + co0 + co_l] = tile[co_l][ci_l * taps + (taps - 1 - tapf)];
+    const float v = tile[co_l][ci_l * taps + (taps - 1 - tapf)];
+    bwd[((long)(ci0 + ci_l) * taps + tapf) * Co_pad + co0 + co_l] = v;
+    if (g6b && taps == 1) {
+      const int k = co0 + co_l;
+      split_store(g6b + ((((long)(k >> 4) * 3) * Ci_pad + ci0 + ci_l) << 4) + (k & 15), (long)Ci_pad << 4, v);
+    }
   }
   if (taps != 9) return;
   // Winograd F(2,3) operands (conv_wino.hip): G g per filter row, u = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)

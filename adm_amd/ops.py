@@ -156,6 +156,8 @@ def _gemm_x6_operands(ent: "_Packed"):
         ent.g6f = torch.empty((3,) + tuple(ent.fwd.shape), device=ent.fwd.device, dtype=torch.bfloat16)
         ent.g6b = torch.empty((3,) + tuple(ent.bwd.shape), device=ent.bwd.device, dtype=torch.bfloat16)
         _resplit_gemm_x6(ent)
+        global _pack_table
+        _pack_table = None           # the one-launch repack table must learn the new destinations
     return ent.g6f, ent.g6b
 
 
@@ -250,7 +252,8 @@ def repack_all():
             rows.append([w.data_ptr(), ent.fwd.data_ptr(), ent.bwd.data_ptr(), co, ci, ks * ks, cop, cip, int(qkv), tiles,
                          0 if ent.wf is None else ent.wf.data_ptr(), 0 if ent.wb is None else ent.wb.data_ptr(),
                          0 if ent.w2f is None else ent.w2f.data_ptr(), 0 if ent.w2b is None else ent.w2b.data_ptr(),
-                         0 if ent.w2f6 is None else ent.w2f6.data_ptr(), 0 if ent.w2b6 is None else ent.w2b6.data_ptr()])
+                         0 if ent.w2f6 is None else ent.w2f6.data_ptr(), 0 if ent.w2b6 is None else ent.w2b6.data_ptr(),
+                         0 if ent.g6f is None else ent.g6f.data_ptr(), 0 if ent.g6b is None else ent.g6b.data_ptr()])
             tiles += (cop // 32) * (cip // 32)         # column 9 = exclusive prefix sum of 32x32 tiles
             ents.append((wref, bref, ks, qkv, ent))
         if not rows:
@@ -271,8 +274,6 @@ def repack_all():
         if b is not None and (qkv or ceil32(co) != co):
             call("adm_permute_vec", ptr(b.detach()), ptr(ent.bias), co, ceil32(co), int(qkv), 0)
         ent.fwd16 = ent.bwd16 = None
-        if ent.g6f is not None:
-            _resplit_gemm_x6(ent)
         ent.key = (w.data_ptr(), w._version, _pack_epoch, ks, qkv, None if b is None else (b.data_ptr(), b._version))
 
 
