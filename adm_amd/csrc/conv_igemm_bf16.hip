@@ -21,7 +21,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmBP {
   const float* x; const unsigned short* w; const float* bias; const float* res; float* y;
-  int M, N, H, W, Hin, Win, Cin, ldx, K, ldy, ldr, ks, up, wrows, tilesN, xbytes, wbytes;
+  int M, N, H, W, Hin, Win, Cin, ldx, K, ldy, ldr, ks, up, wrows, tilesN, xbytes, wbytes, abf;
 };
 
 constexpr int BK = 64;
@@ -33,10 +33,14 @@ __device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
   return r;
 }
 
-template <int BM, int BN, int WM, int WN, bool UP>
+// ABF: the A operand is ALREADY bf16 in HBM (x16[B][H][W][ldx] bf16, e.g. written by adm_gn_fwd_bf16out): 16-byte loads of 8
+// channels go straight to LDS -- half the bytes, no conversion.  Values equal what the f32 path would round to: bit-identical results.
+template <int BM, int BN, int WM, int WN, bool UP, bool ABF>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmBP p) {
   constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32);
-  constexpr int AI = BM / 16;          // A: fp32 float4 (4 k) per thread per stage: BM rows x 16 quads / 256
+  constexpr int AI = ABF ? BM / 32 : BM / 16;      // A: f32 float4 (4 k) per thread per stage: BM rows x 16 quads / 256; bf16: x 8 octets
+  constexpr int ARS = ABF ? 32 : 16;               // row step between a thread's A items
+  constexpr int AEB = ABF ? 2 : 4;                 // bytes per A element
   constexpr int BI = BN / 32;          // B: 8 bf16 (16 bytes) per thread per stage: BN rows x 8 octets / 256
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) __bf16 smem_b[];
@@ -58,13 +62,13 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmBP p) {
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, p.wbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
-  // A loader: thread owns fp32 quad a_c4 (of 16) of rows a_r0 + 16 i
-  const int a_c4 = tid & 15, a_r0 = tid >> 4;
+  // A loader: thread owns fp32 quad a_c4 (of 16) of rows a_r0 + 16 i  (bf16 A: octet a_c4 (of 8) of rows a_r0 + 32 i)
+  const int a_c4 = ABF ? (tid & 7) : (tid & 15), a_r0 = ABF ? (tid >> 3) : (tid >> 4);
   unsigned a_pix[AI], a_mask[AI], a_voff[AI];
   const int pad = p.ks >> 1;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    int m = m0 + a_r0 + 16 * i;
+    int m = m0 + a_r0 + ARS * i;
     bool ok = m < p.M;
     int mm = ok ? m : 0;
     int ox = mm % p.W;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmBP p) {
     if (UP) mask |= ((unsigned)(oy & 1) << 16) | ((unsigned)(ox & 1) << 17);
     a_mask[i] = mask;
     int py = UP ? (oy >> 1) : oy, px = UP ? (ox >> 1) : ox;
-    a_pix[i] = (unsigned)(((b * p.Hin + py) * p.Win + px) * p.ldx + a_c4 * 4) * 4u;
+    a_pix[i] = (unsigned)(((b * p.Hin + py) * p.Win + px) * p.ldx + a_c4 * (ABF ? 8 : 4)) * (unsigned)AEB;
     a_voff[i] = OOB;
   }
   // B loader: thread owns bf16 octet b_c8 (of 8) of rows b_r0 + 32 i
@@ -117,13 +121,13 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmBP p) {
           int qy = ((py + dy + 2) >> 1) - 1, qx = ((px + dx + 2) >> 1) - 1;
           off = (qy * p.Win + qx) * p.ldx;
         }
-        a_voff[i] = v ? a_pix[i] + (unsigned)(off * 4) : OOB;
+        a_voff[i] = v ? a_pix[i] + (unsigned)(off * AEB) : OOB;
       }
     }
     const int c0 = ld_cc * BK;
 #pragma unroll
     for (int i = 0; i < AI; ++i)
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[i], c0 * 4, 0));
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)a_voff[i], c0 * AEB, 0));
     const int kb = (tap * p.Cin + c0) * 2;
 #pragma unroll
     for (int i = 0; i < BI; ++i)
@@ -134,8 +138,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmBP p) {
     __bf16* Ab = As + buf * BM * LROW;
     __bf16* Bb = Bs + buf * BN * LROW;
 #pragma unroll
-    for (int i = 0; i < AI; ++i)
-      *reinterpret_cast<bf16x4*>(&Ab[(a_r0 + 16 * i) * LROW + a_c4 * 4]) = cvt4(ra[i]);
+    for (int i = 0; i < AI; ++i) {
+      if (ABF) *reinterpret_cast<f32x4*>(&Ab[(a_r0 + ARS * i) * LROW + a_c4 * 8]) = ra[i];       // 8 bf16, as loaded
+      else *reinterpret_cast<bf16x4*>(&Ab[(a_r0 + ARS * i) * LROW + a_c4 * 4]) = cvt4(ra[i]);
+    }
 #pragma unroll
     for (int i = 0; i < BI; ++i)
       *reinterpret_cast<f32x4*>(&Bb[(b_r0 + 32 * i) * LROW + b_c8 * 8]) = rb[i];
@@ -219,25 +225,26 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmBP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool UP>
+template <int BM, int BN, int WM, int WN, bool UP, bool ABF>
 int launch_b_up(IgemmBP p, hipStream_t st) {
   static bool attr_set = false;
   constexpr int smem = 2 * (BM + BN) * LROW * 2;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<BM, BN, WM, WN, UP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<BM, BN, WM, WN, UP, ABF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   p.tilesN = adm_cdiv(p.N, BN);
   long grid = (long)adm_cdiv(p.M, BM) * p.tilesN;
-  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, UP>), dim3((unsigned)grid), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, UP, ABF>), dim3((unsigned)grid), dim3(256), smem, st, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
 template <int BM, int BN, int WM, int WN>
 int launch_b(IgemmBP p, hipStream_t st) {
-  return p.up ? launch_b_up<BM, BN, WM, WN, true>(p, st) : launch_b_up<BM, BN, WM, WN, false>(p, st);
+  if (p.abf) return p.up ? launch_b_up<BM, BN, WM, WN, true, true>(p, st) : launch_b_up<BM, BN, WM, WN, false, true>(p, st);
+  return p.up ? launch_b_up<BM, BN, WM, WN, true, false>(p, st) : launch_b_up<BM, BN, WM, WN, false, false>(p, st);
 }
 
 __global__ void pack_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
@@ -258,9 +265,28 @@ extern "C" int adm_f32_to_bf16(const float* src, unsigned short* dst, long n, hi
   return ADM_OK;
 }
 
+static int conv_fwd_bf16_impl(const float* x, const unsigned short* wp, const float* bias, const float* res, float* y, int B, int H, int W,
+                              int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks, int up, int tile, int abf,
+                              hipStream_t stream);
+
 extern "C" int adm_conv_fwd_bf16(const float* x, const unsigned short* wp, const float* bias, const float* res,
                                  float* y, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                                  int ks, int up, int tile, hipStream_t stream) {
+  return conv_fwd_bf16_impl(x, wp, bias, res, y, B, H, W, Cin, ldx, N, wrows, ldy, ldr, ks, up, tile, 0, stream);
+}
+
+// the same with the activation ALREADY stored as bf16: x16[B][Hin][Win][ldx] (bf16 elements; ldx % 8 == 0)
+extern "C" int adm_conv_fwd_bf16a(const void* x16, const unsigned short* wp, const float* bias, const float* res, float* y, int B,
+                                  int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks, int up, int tile,
+                                  hipStream_t stream) {
+  if (ldx & 7) return ADM_EINVAL;
+  return conv_fwd_bf16_impl(static_cast<const float*>(x16), wp, bias, res, y, B, H, W, Cin, ldx, N, wrows, ldy, ldr, ks, up, tile, 1,
+                            stream);
+}
+
+static int conv_fwd_bf16_impl(const float* x, const unsigned short* wp, const float* bias, const float* res, float* y, int B, int H, int W,
+                              int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks, int up, int tile, int abf,
+                              hipStream_t stream) {
   if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
   if ((Cin % BK) || (ldx & 3) || (ks != 1 && ks != 3) || N <= 0 || wrows < N) return ADM_EINVAL;
   if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
@@ -270,8 +296,8 @@ extern "C" int adm_conv_fwd_bf16(const float* x, const unsigned short* wp, const
   p.M = B * H * W; p.N = N; p.H = H; p.W = W;
   p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.K = ks * ks * Cin; p.ldy = ldy; p.ldr = ldr; p.ks = ks; p.up = up; p.wrows = wrows;
-  p.tilesN = 0;
-  const long xb = (long)B * p.Hin * p.Win * ldx * 4, wb = (long)wrows * p.K * 2;
+  p.tilesN = 0; p.abf = abf;
+  const long xb = (long)B * p.Hin * p.Win * ldx * (abf ? 2 : 4), wb = (long)wrows * p.K * 2;
   if (xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;
   p.xbytes = (int)xb; p.wbytes = (int)wb;
   if (tile < 0) {

@@ -14,15 +14,28 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 struct WgradBP {
   const float* x; const float* dy; float* dwp;
-  int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes;
+  int P, H, W, Hin, Win, Cin, ldx, Cout, lddy, ks, up, tilesN, chunk, atomic, lw, lh, xbytes, dybytes, xbf;
 };
 
 constexpr int PK = 64;            // pixels per stage
 constexpr int LROW = PK + 8;      // bf16 per LDS row (144 bytes)
 
-template <int TM, int TN, bool FAST>
+// XBF: x is ALREADY bf16 in HBM (the bf16-storage mode: written by adm_gn_fwd_bf16out): 8-byte loads of a channel quad, widened to
+// the f32 values the f32 path would have rounded to -- bit-identical results, half the x traffic.
+template <int TM, int TN, bool FAST, bool XBF>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBP p) {
   constexpr int WM = 2, WN = 2;
+  constexpr unsigned XEB = XBF ? 2u : 4u;          // bytes per x element
+  auto load_x = [](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff) -> f32x4 {
+    if constexpr (XBF) {
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t h = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0));
+      return f32x4{__uint_as_float(h[0] << 16), __uint_as_float(h[0] & 0xFFFF0000u), __uint_as_float(h[1] << 16),
+                   __uint_as_float(h[1] & 0xFFFF0000u)};
+    } else {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
+    }
+  };
   constexpr int MT = TM / (WM * 32), NT = TN / (WN * 32);
   constexpr int AU = TM / 32, BU = TN / 32;        // (32 pixel x 16 channel) units per wave per stage
   __shared__ __attribute__((aligned(16))) __bf16 As[2][TM][LROW];
@@ -46,9 +59,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBP p) {
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
-  const int shift = (dy_ * p.W + dx_) * p.ldx;
-  const __amdgpu_buffer_rsrc_t rs_xt =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + shift, 0, max(0, p.xbytes - shift * 4), 0x00020000);
+  const int shift = (dy_ * p.W + dx_) * p.ldx;       // elements
+  const __amdgpu_buffer_rsrc_t rs_xt = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(const_cast<float*>(p.x)) + (long)shift * (int)XEB, 0, max(0, p.xbytes - shift * (int)XEB), 0x00020000);
   // (a tap shift larger than the whole tensor -- 1 x 2 images -- must not wrap num_records around: 0 records = every
   //  access out of range = zeros, which is what such a tap contributes)
 
@@ -66,12 +79,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBP p) {
     const int u = wid * BU + i;
     b_pix[i] = (u & 1) * 32 + 2 * lp;
     b_row[i] = ((u >> 1) * 4 + lq) * 4;
-    b_colb[i] = (ci0 + b_row[i] < p.Cin) ? (unsigned)(ci0 + b_row[i]) * 4u : OOB;
+    b_colb[i] = (ci0 + b_row[i] < p.Cin) ? (unsigned)(ci0 + b_row[i]) * XEB : OOB;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int px = b_pix[i] + e;
       const bool xv = (unsigned)((px & (p.W - 1)) + dx_) < (unsigned)p.W;
-      b_voff[i][e] = (xv && b_colb[i] != OOB) ? (unsigned)(px * p.ldx) * 4u + b_colb[i] : OOB;
+      b_voff[i][e] = (xv && b_colb[i] != OOB) ? (unsigned)(px * p.ldx) * XEB + b_colb[i] : OOB;
     }
   }
 
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBP p) {
         ra[i][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)vo, a_soff, 0));
       }
     if constexpr (FAST) {
-      const int b_soff = pb * p.ldx * 4;
+      const int b_soff = pb * p.ldx * (int)XEB;
       const int U = pb >> p.lw;
 #pragma unroll
       for (int i = 0; i < BU; ++i)
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBP p) {
             const int iy = ((U + (px >> p.lw)) & (p.H - 1)) + dy_;
             v = v && (unsigned)iy < (unsigned)p.H;
           }
-          rb[i][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xt, (int)(v ? b_voff[i][e] : OOB), b_soff, 0));
+          rb[i][e] = load_x(rs_xt, v ? b_voff[i][e] : OOB, b_soff);
         }
     } else {
 #pragma unroll
@@ -116,8 +129,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBP p) {
           int iy = oy + dy_, ix = ox + dx_;
           bool v = pp < pend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && b_colb[i] != OOB;
           if (p.up) { iy >>= 1; ix >>= 1; }
-          unsigned voff = v ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.ldx) * 4u + b_colb[i] : OOB;
-          rb[i][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0));
+          unsigned voff = v ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.ldx) * XEB + b_colb[i] : OOB;
+          rb[i][e] = load_x(rs_x, voff, 0);
         }
     }
   };
@@ -197,25 +210,44 @@ int launch_wb(WgradBP p, int splits, hipStream_t st) {
   p.tilesN = adm_cdiv(p.Cin, TN);
   dim3 grid(adm_cdiv(p.Cout, TM) * p.tilesN, p.ks * p.ks, splits);
   const bool fast = p.lw >= 0 && p.W <= 32 && !p.up;
-  if (fast) hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN, false>), grid, dim3(256), 0, st, p);
+  if (p.xbf) {
+    if (fast) hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN, false, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (fast) hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN, true, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN, false, false>), grid, dim3(256), 0, st, p);
+  }
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
 
 }  // namespace
 
+static int conv_wgrad_bf16_impl(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx, int Cout, int lddy,
+                                int ks, int up, int splits, int xbf, hipStream_t stream);
+
 extern "C" int adm_conv_wgrad_bf16(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx,
                                    int Cout, int lddy, int ks, int up, int splits, hipStream_t stream) {
+  return conv_wgrad_bf16_impl(x, dy, dwp, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, 0, stream);
+}
+
+// the same with the saved activation ALREADY stored as bf16: x16[B][Hin][Win][ldx] (bf16 elements)
+extern "C" int adm_conv_wgrad_bf16a(const void* x16, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx, int Cout,
+                                    int lddy, int ks, int up, int splits, hipStream_t stream) {
+  return conv_wgrad_bf16_impl(static_cast<const float*>(x16), dy, dwp, B, H, W, Cin, ldx, Cout, lddy, ks, up, splits, 1, stream);
+}
+
+static int conv_wgrad_bf16_impl(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx, int Cout, int lddy,
+                                int ks, int up, int splits, int xbf, hipStream_t stream) {
   if (!x || !dy || !dwp || B <= 0 || H <= 0 || W <= 0) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3) || (ks != 1 && ks != 3)) return ADM_EINVAL;
   if (up && ((H & 1) || (W & 1))) return ADM_EINVAL;
-  if (((uintptr_t)x | (uintptr_t)dy) & 15) return ADM_EINVAL;
+  if ((((uintptr_t)x) & (xbf ? 7 : 15)) || (((uintptr_t)dy) & 15)) return ADM_EINVAL;
   WgradBP p;
-  p.x = x; p.dy = dy; p.dwp = dwp;
+  p.x = x; p.dy = dy; p.dwp = dwp; p.xbf = xbf;
   p.P = B * H * W; p.H = H; p.W = W; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
   p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.ks = ks; p.up = up; p.tilesN = 0;
-  const long xb = (long)B * p.Hin * p.Win * ldx * 4, db = (long)p.P * lddy * 4;
+  const long xb = (long)B * p.Hin * p.Win * ldx * (xbf ? 2 : 4), db = (long)p.P * lddy * 4;
   if (xb >= (1L << 31) || db >= (1L << 31)) return ADM_EINVAL;
   p.xbytes = (int)xb; p.dybytes = (int)db;
   auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };

@@ -12,6 +12,18 @@
 
 namespace {
 
+// y element store: f32x4, or (out_bf16) four bf16 (round to nearest even) -- the bf16-storage mode of BASELINE configs[2]
+__device__ __forceinline__ void gn_store4(float* y, long quad_idx, f32x4 u, int out_bf16) {
+  if (out_bf16) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t h;
+    h[0] = (__bf16)u[0]; h[1] = (__bf16)u[1]; h[2] = (__bf16)u[2]; h[3] = (__bf16)u[3];
+    reinterpret_cast<bf16x4_t*>(y)[quad_idx] = h;
+  } else {
+    reinterpret_cast<f32x4*>(y)[quad_idx] = u;
+  }
+}
+
 __host__ __device__ inline int gn_rows_par(int C) { int r = 256 / (C / 4); return r < 1 ? 1 : r; }
 
 // ---------------------------------------------------------------- forward: moments
@@ -99,7 +111,7 @@ __global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restr
 __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ ss, long ss_bstride, float* __restrict__ y, int HW, int C,
-                                int G, int rows_per_split, int silu, float drop_p, uint64_t seed) {
+                                int G, int rows_per_split, int silu, float drop_p, uint64_t seed, int out_bf16) {
   const int C4 = C >> 2, R = blockDim.x / C4;
   const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
   const int b = blockIdx.x;
@@ -117,7 +129,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
     cb[k] = (beta[c] - mean * ga) * sc1 + sh;
   }
   const f32x4* xb = reinterpret_cast<const f32x4*>(x + (long)b * HW * C);
-  f32x4* yb = reinterpret_cast<f32x4*>(y + (long)b * HW * C);
+  const long ybase = (long)b * HW * C4;             // in channel quads
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 #pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
@@ -128,7 +140,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
       for (int k = 0; k < 4; ++k) u[k] = silu_f(u[k]);
     }
     if (drop_p > 0.f) u *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + cq, drop_p, inv_keep);
-    yb[(long)hw * C4 + cq] = u;
+    gn_store4(y, ybase + (long)hw * C4 + cq, u, out_bf16);
   }
 }
 
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 3)) void gn_fused_fwd_ker
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
                                                            long ss_bstride, float* __restrict__ y,
                                                            float* __restrict__ stats, int HW, int C, int G, int Cc,
-                                                           float eps, int silu, float drop_p, uint64_t seed) {
+                                                           float eps, int silu, float drop_p, uint64_t seed, int out_bf16) {
   extern __shared__ float sm[];                    // [R][Cc][2] partials | [Gc][2] mean, rstd
   const int Cc4 = Cc >> 2, R = blockDim.x / Cc4, C4 = C >> 2;
   const int cq = threadIdx.x % Cc4, ry = threadIdx.x / Cc4;
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 3)) void gn_fused_fwd_ker
     ca[k] = ga * sc1;
     cb[k] = (beta[c] - mean * ga) * sc1 + sh;
   }
-  f32x4* yb = reinterpret_cast<f32x4*>(y + (long)b * HW * C + c0);
+  const long ybase = (long)b * HW * C4 + (c0 >> 2);  // in channel quads
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 3)) void gn_fused_fwd_ker
       for (int k = 0; k < 4; ++k) u[k] = silu_f(u[k]);
     }
     if (drop_p > 0.f) u *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + (c0 >> 2) + cq, drop_p, inv_keep);
-    yb[(long)hw * C4 + cq] = u;
+    gn_store4(y, ybase + (long)hw * C4 + cq, u, out_bf16);
     __builtin_amdgcn_sched_barrier(0);            // one row at a time: interleaving the rows' hashes / exponentials costs registers
   }
 }
@@ -567,35 +579,60 @@ extern "C" int adm_gn_stats(const float* x, float* stats, double* ws, int B, int
   return ADM_OK;
 }
 
-extern "C" int adm_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta,
-                            const float* ss, long ss_bstride, float* y, int B, int HW, int C, int G, int silu,
-                            float drop_p, uint64_t seed, hipStream_t stream) {
+static int gn_apply_impl(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss, long ss_bstride,
+                         float* y, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, int out_bf16,
+                         hipStream_t stream) {
   if (!x || !stats || !gamma || !beta || !y || !gn_shape_ok(B, HW, C, G) || drop_p < 0.f || drop_p >= 1.f)
     return ADM_EINVAL;
   int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(B, S), dim3(gn_threads(C)), 0, stream, x, stats, gamma, beta, ss,
-                     ss_bstride, y, HW, C, G, rows, silu, drop_p, seed);
+                     ss_bstride, y, HW, C, G, rows, silu, drop_p, seed, out_bf16);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
 
+extern "C" int adm_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta,
+                            const float* ss, long ss_bstride, float* y, int B, int HW, int C, int G, int silu,
+                            float drop_p, uint64_t seed, hipStream_t stream) {
+  return gn_apply_impl(x, stats, gamma, beta, ss, ss_bstride, y, B, HW, C, G, silu, drop_p, seed, 0, stream);
+}
+
+static int gn_fwd_impl(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+                       long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
+                       int out_bf16, hipStream_t stream);
+
 extern "C" int adm_gn_fwd(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
                           long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p,
                           uint64_t seed, hipStream_t stream) {
+  return gn_fwd_impl(x, stats, ws, gamma, beta, ss, ss_bstride, y, B, HW, C, G, eps, silu, drop_p, seed, 0, stream);
+}
+
+// the same with y stored as bf16 (round to nearest even): y16[B][HW][C] -- the bf16-storage mode (BASELINE configs[2]) feeds the
+// following conv's A operand without a conversion pass; statistics, affine map and activation stay f32
+extern "C" int adm_gn_fwd_bf16out(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+                                  long ss_bstride, void* y16, int B, int HW, int C, int G, float eps, int silu, float drop_p,
+                                  uint64_t seed, hipStream_t stream) {
+  return gn_fwd_impl(x, stats, ws, gamma, beta, ss, ss_bstride, static_cast<float*>(y16), B, HW, C, G, eps, silu, drop_p, seed, 1,
+                     stream);
+}
+
+static int gn_fwd_impl(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+                       long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
+                       int out_bf16, hipStream_t stream) {
   if (!x || !stats || !ws || !gamma || !beta || !y || !gn_shape_ok(B, HW, C, G) || drop_p < 0.f || drop_p >= 1.f)
     return ADM_EINVAL;
   const GnPlan pl = g_gn_fused ? gn_fused_plan(HW, C, G, false) : GnPlan{0, 0, 0};
   if (pl.Cc == 0) {
     int rc = adm_gn_stats(x, stats, ws, B, HW, C, G, eps, stream);
     if (rc != ADM_OK) return rc;
-    return adm_gn_apply(x, stats, gamma, beta, ss, ss_bstride, y, B, HW, C, G, silu, drop_p, seed, stream);
+    return gn_apply_impl(x, stats, gamma, beta, ss, ss_bstride, y, B, HW, C, G, silu, drop_p, seed, out_bf16, stream);
   }
   const int Cc = pl.Cc, R = pl.threads / (Cc / 4), Gc = Cc / (C / G);
   const size_t smem = ((size_t)R * Cc * 2 + (size_t)((Gc * 2 + 1) & ~1)) * sizeof(float) + (size_t)Cc * sizeof(double);
   const dim3 grid(C / Cc, B), block(pl.threads);
 #define GN_FWD(MAXR, THREADS)                                                                                                 \
   hipLaunchKernelGGL((gn_fused_fwd_kernel<MAXR, THREADS>), grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, \
-                     HW, C, G, Cc, eps, silu, drop_p, seed)
+                     HW, C, G, Cc, eps, silu, drop_p, seed, out_bf16)
   if (pl.rows <= 2) GN_FWD(2, 256);
   else if (pl.rows <= 8) GN_FWD(8, 256);
   else GN_FWD(14, 256);

@@ -54,6 +54,9 @@ _SIGS = {
     "adm_unpack_wgrad_splits": [P, I, P, I, I, I, I, I, I, I, P, P, P],
     "adm_conv_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_fwd_bf16a": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_conv_wgrad_bf16a": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "adm_gn_fwd_bf16out": [P, P, P, P, P, P, L, P, I, I, I, I, F, I, F, U, P],
     "adm_f32_to_bf16": [P, P, L, P],
     "adm_pack_weight": [P, P, P, I, I, I, I, I, I, P],
     "adm_pack_weight_table": [P, I, L, P],

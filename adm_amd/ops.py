@@ -88,6 +88,16 @@ BF16X6 = os.environ.get("ADM_BF16X6", "1") != "0"
 DETERMINISTIC = os.environ.get("ADM_DETERMINISTIC", "0") == "1"
 
 
+# In the bf16 mode the GroupNorm(+SiLU+dropout) outputs that feed a conv are STORED as bf16 in HBM (BASELINE configs[2]: "bf16
+# activations"): adm_gn_fwd_bf16out writes them, adm_conv_fwd_bf16a / adm_conv_wgrad_bf16a read them directly (half the bytes, no
+# conversion pass; bit-identical to rounding on load).  The residual stream, statistics, gradients and master weights stay f32.
+BF16_STORAGE = os.environ.get("ADM_BF16_STORAGE", "1") != "0"
+
+
+def bf16_storage() -> bool:
+    return COMPUTE == "bf16" and BF16_STORAGE
+
+
 def set_compute_precision(mode: str):
     global COMPUTE
     if mode not in ("f32", "bf16"):
@@ -394,6 +404,9 @@ class _Conv(torch.autograd.Function):
                 raise RuntimeError(f"residual shape {tuple(res.shape)} != output {tuple(y.shape)}")
         bf16 = COMPUTE == "bf16"
         use_bf16 = bf16 and cip % 64 == 0
+        x16 = getattr(x, "_adm_bf16", None)          # bf16-storage mode: the values of this input live here (x is the f32 carrier)
+        if x16 is not None and not use_bf16:
+            raise RuntimeError("a bf16-stored activation reached a conv that does not run in the bf16 mode")
         wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv
         wq2 = _wino2_operands(weight, pk)[0] if (wino and _use_wino2d(B, Ho, Wo, ks, up, tile)) else None
         wq = _wino_operands(weight, pk)[0] if (wino and wq2 is None) else None
@@ -405,12 +418,12 @@ class _Conv(torch.autograd.Function):
                 call("adm_gemm_x6", ptr(x), ptr(_gemm_x6_operands(pk)[0]), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
                      cop, cop, cop)
             elif use_bf16:
-                call("adm_conv_fwd_bf16", ptr(x), ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho,
-                     Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
+                call("adm_conv_fwd_bf16a" if x16 is not None else "adm_conv_fwd_bf16", ptr(x16 if x16 is not None else x),
+                     ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
                 _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq, wq2,
                           pk.w2f6 if (BF16X6 and wq2 is not None) else None)
-        ctx.save_for_backward(x, weight, bias)
+        ctx.save_for_backward(x16 if x16 is not None else x, weight, bias)      # (the carrier is not kept)
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
         return y
 
@@ -473,7 +486,8 @@ class _Conv(torch.autograd.Function):
                 with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"{kind.replace('_', '-')} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16:
-                        call("adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho, Wo, cip, cip, cop, cop, ks, int(up), 0)
+                        call("adm_conv_wgrad_bf16a" if x.dtype == torch.bfloat16 else "adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho,
+                             Wo, cip, cip, cop, cop, ks, int(up), 0)
                     elif det and g6_w:
                         call("adm_gemm_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B * Ho * Wo, cip, cip, cop, cop, splits)
                     elif g6_w:
@@ -590,7 +604,7 @@ def next_dropout_seed() -> int:
 
 class _GroupNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed, groups=0, eps=1e-5, fork=False):
+    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed, groups=0, eps=1e-5, fork=False, out_bf16=False):
         x_in = x
         x = _chk(x, "x")
         B, H, W, C = x.shape
@@ -609,8 +623,16 @@ class _GroupNormAct(torch.autograd.Function):
                 raise RuntimeError(f"scale/shift shape {tuple(ssc.shape)} does not match C={C}, B={B}")
             bstride = 0 if ssc.shape[0] == 1 else 2 * C
         y = torch.empty_like(x)
-        call("adm_gn_fwd", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), B, HW, C, G, float(eps),
-             int(silu), float(drop_p), seed)
+        if out_bf16 and C % 64 == 0:
+            # bf16 storage: the VALUES go to y16; `y` is only the f32 shape / dtype carrier autograd needs between this node and the
+            # conv that consumes it (its storage is never written or read, and is released as soon as the conv has run)
+            global _gn_bf16_out
+            _gn_bf16_out = y16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+            call("adm_gn_fwd_bf16out", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y16), B, HW, C, G, float(eps),
+                 int(silu), float(drop_p), seed)
+        else:
+            call("adm_gn_fwd", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), B, HW, C, G, float(eps),
+                 int(silu), float(drop_p), seed)
         prof.__exit__()
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (G, S, bstride, silu, drop_p, seed)
@@ -623,7 +645,7 @@ class _GroupNormAct(torch.autograd.Function):
         x, gamma, beta, ss, stats = ctx.saved_tensors
         G, S, bstride, silu, drop_p, seed = ctx.meta
         if dy is None:    # only the pass-through output was used
-            return dxr, None, None, None, None, None, None, None, None, None
+            return dxr, None, None, None, None, None, None, None, None, None, None
         dy = _chk(dy, "dy")
         add = None if dxr is None else _chk(dxr, "residual gradient")
         B, H, W, C = x.shape
@@ -644,23 +666,39 @@ class _GroupNormAct(torch.autograd.Function):
                  ptr(add), ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
         if direct:
             _notify(gamma); _notify(beta)
-            return dx, None, None, dss, None, None, None, None, None, None
-        return dx, dgamma, dbeta, dss, None, None, None, None, None, None
+            return dx, None, None, dss, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None
 
 
-def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5):
+_gn_bf16_out = None      # the bf16 values of the last bf16-storage GroupNorm forward (picked up by the wrapper below)
+
+
+def _attach_bf16(y):
+    """Hands the bf16 values of a bf16-storage GroupNorm output to its consumer: conv2d looks for `_adm_bf16` on its input."""
+    global _gn_bf16_out
+    if _gn_bf16_out is not None:
+        y._adm_bf16, _gn_bf16_out = _gn_bf16_out, None
+    return y
+
+
+def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5, to_conv=False):
     """groups = 0: the UNet's min(32, C // 4) (uncond_unet.py:119-129); the KL autoencoder passes 32 / 1e-6
-    (ddm/encoder_decoder.py:56-57)."""
-    return _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps))
+    (ddm/encoder_decoder.py:56-57).  to_conv=True promises that the ONLY consumer of the result is ops.conv2d: in the bf16-storage
+    mode the values are then written as bf16 and the returned f32 tensor is an unwritten carrier (see _GroupNormAct.forward)."""
+    out16 = bool(to_conv) and bf16_storage()
+    y = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), False, out16)
+    return _attach_bf16(y) if out16 else y
 
 
-def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5):
+def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5, to_conv=False):
     """(group_norm_act(x), x): the second output is x itself, to be used by the residual branch of a block.  In backward
     the residual branch's gradient arrives together with the normalised branch's, and is added inside the GroupNorm
     backward kernel instead of by a separate autograd accumulation pass (4 instead of 12 bytes per element)."""
     if not (torch.is_grad_enabled() and x.requires_grad):
-        return group_norm_act(x, gamma, beta, scale_shift, silu=silu, drop_p=drop_p, seed=seed, groups=groups, eps=eps), x
-    return _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), True)
+        return group_norm_act(x, gamma, beta, scale_shift, silu=silu, drop_p=drop_p, seed=seed, groups=groups, eps=eps, to_conv=to_conv), x
+    out16 = bool(to_conv) and bf16_storage()
+    y, xo = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), True, out16)
+    return (_attach_bf16(y) if out16 else y), xo
 
 
 # ------------------------------------------------------------------------------------------------

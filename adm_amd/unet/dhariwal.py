@@ -92,14 +92,15 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_channels))
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
-    def forward(self, x, scale_shift=None, silu=False, drop_p=0.0):
+    def forward(self, x, scale_shift=None, silu=False, drop_p=0.0, to_conv=False):
+        """to_conv: the result feeds ops.conv2d and nothing else (lets the bf16 mode store it as bf16, ops.group_norm_act)."""
         seed = ops.next_dropout_seed() if drop_p > 0 else 0
-        return ops.group_norm_act(x, self.weight, self.bias, scale_shift, silu=silu, drop_p=drop_p, seed=seed)
+        return ops.group_norm_act(x, self.weight, self.bias, scale_shift, silu=silu, drop_p=drop_p, seed=seed, to_conv=to_conv)
 
-    def fork(self, x, silu=False):
+    def fork(self, x, silu=False, to_conv=False):
         """(norm(x), x): x comes back for the residual branch so that both gradients are summed inside the GroupNorm
         backward kernel (ops.group_norm_act_fork)."""
-        return ops.group_norm_act_fork(x, self.weight, self.bias, None, silu=silu)
+        return ops.group_norm_act_fork(x, self.weight, self.bias, None, silu=silu, to_conv=to_conv)
 
 
 class UNetBlock(nn.Module):
@@ -129,13 +130,14 @@ class UNetBlock(nn.Module):
             self.proj = Conv2d(out_channels, out_channels, 1, **init_zero)
 
     def forward(self, x, emb):
-        n0, x = self.norm0.fork(x, silu=True)         # x feeds the normalised branch AND the residual / skip branch
+        # (to_conv: these normalised tensors go straight into a conv -- conv0 resamples first when it down-samples)
+        n0, x = self.norm0.fork(x, silu=True, to_conv=not self.conv0.down)    # x feeds the normalised branch AND the residual / skip branch
         h = self.conv0(n0)
         p = self.dropout if self.training else 0.0
-        h = self.norm1(h, self.affine(emb), silu=True, drop_p=p)
+        h = self.norm1(h, self.affine(emb), silu=True, drop_p=p, to_conv=True)
         h = self.conv1(h, residual=x if self.skip is None else self.skip(x))
         if self.num_heads:
-            n2, h = self.norm2.fork(h)
+            n2, h = self.norm2.fork(h, to_conv=True)
             a = ops.attention(self.qkv(n2), self.num_heads)
             h = self.proj(a, residual=h)
         return h
@@ -258,7 +260,7 @@ class DhariwalUNet(nn.Module):
                 r = ratios.pop() if ratios is not None else 1.0
                 x = ops.concat_channels(x, stack.pop(), r)
             x = block(x, emb)
-        return out_conv(out_norm(x, silu=True))
+        return out_conv(out_norm(x, silu=True, to_conv=True))
 
     def forward(self, x, noise_labels, class_labels=None, augment_labels=None, **kwargs):
         """x: NHWC [B,H,W,32] (3 real channels).  Returns (F_x, F_y) NHWC with 32 padded channels

@@ -173,6 +173,16 @@ int adm_conv_fwd_bf16(const float* x, const unsigned short* wp16, const float* b
                       int tile, hipStream_t stream);
 int adm_conv_wgrad_bf16(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx, int Cout,
                         int lddy, int ks, int up, int splits, hipStream_t stream);
+/* bf16-STORAGE variants (BASELINE configs[2]): the activation operand is already bf16 in HBM (written by adm_gn_fwd_bf16out), so
+ * the kernels read half the bytes and skip the conversion; results are bit-identical to the f32-activation entry points above. */
+int adm_conv_fwd_bf16a(const void* x16, const unsigned short* wp16, const float* bias, const float* res, float* y, int B, int H, int W,
+                       int Cin, int ldx, int N, int wrows, int ldy, int ldr, int ks, int up, int tile, hipStream_t stream);
+int adm_conv_wgrad_bf16a(const void* x16, const float* dy, float* dwp, int B, int H, int W, int Cin, int ldx, int Cout, int lddy, int ks,
+                         int up, int splits, hipStream_t stream);
+/* adm_gn_fwd with y stored as bf16 (round to nearest even): y16[B][HW][C] */
+int adm_gn_fwd_bf16out(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+                       long ss_bstride, void* y16, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
+                       hipStream_t stream);
 int adm_f32_to_bf16(const float* src, unsigned short* dst, long n, hipStream_t stream);
 
 /* OIHW [Co][Ci][ks][ks] (the reference's parameter layout, uncond_unet.py:85) ->

@@ -119,3 +119,50 @@ def test_unet_bf16_vs_f32_end_to_end(ops_bf16):
         assert float((u - v).abs().max()) > 0          # the bf16 path really ran
     cos = float(torch.dot(a16[2].double(), a32[2].double()) / (a16[2].double().norm() * a32[2].double().norm()))
     assert cos >= 0.999, cos
+
+
+@pytest.mark.parametrize("C,H,drop,with_ss", [(192, 32, 0.1, True), (384, 16, 0.0, False), (768, 8, 0.1, True), (64, 4, 0.0, True)])
+def test_group_norm_bf16_storage_output(ops_bf16, C, H, drop, with_ss):
+    """bf16-storage mode (BASELINE configs[2], 'bf16 activations'): adm_gn_fwd_bf16out must write exactly the round-to-nearest-even
+    bf16 of what adm_gn_fwd writes in f32 -- multi-pass (32x32) and one-launch (<= 16x16) kernels, with scale/shift and dropout."""
+    ops = ops_bf16
+    B = 4
+    x = fill.hash_tensor((B, H, H, C), f"gsx{C}{H}", 1.5).cuda()
+    g, b = (1 + fill.hash_tensor((C,), "gsg", 0.2)).cuda(), fill.hash_tensor((C,), "gsb", 0.1).cuda()
+    ss = fill.hash_tensor((B, 2 * C), "gss", 0.1).cuda() if with_ss else None
+    y32 = ops.group_norm_act(x, g, b, ss, silu=True, drop_p=drop, seed=1234)
+    carrier = ops.group_norm_act(x, g, b, ss, silu=True, drop_p=drop, seed=1234, to_conv=True)
+    y16 = carrier._adm_bf16
+    assert y16.dtype == torch.bfloat16 and y16.shape == x.shape
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+
+
+def test_unet_bf16_storage_equals_rounding_on_load(ops_bf16, monkeypatch):
+    """The storage mode changes WHERE the rounding happens, not what is computed: the forward outputs of the reduced UNet are
+    bit-identical with ADM_BF16_STORAGE on (bf16 GroupNorm outputs read directly by the convs) and off (f32 outputs rounded in the
+    conv loaders); the parameter gradients agree to the run-to-run noise of the bf16 weight-gradient kernel's float atomics."""
+    ops = ops_bf16
+    from adm_amd.unet.uncond_unet import EDMPrecond
+    cfg = unet_ref.default_cfg(variant="uncond_unet", model_channels=64, num_blocks=1, dropout=0.0)
+    kw = {k: cfg[k] for k in ("model_channels", "channel_mult", "channel_mult_emb", "num_blocks", "attn_resolutions",
+                              "dropout", "augment_dim")}
+    m = EDMPrecond(img_resolution=32, img_channels=3, **kw)
+    m.load_state_dict(fill.filled_state_dict(unet_ref.param_shapes(cfg)))
+    m = m.cuda().eval()
+    x = fill.hash_tensor((2, 3, 32, 32), "x", 1.0).cuda()
+    sigma = torch.tensor([0.05, 0.7]).cuda()
+    gx = fill.hash_tensor((2, 3, 32, 32), "gx", 1.0).cuda()
+
+    def run(storage):
+        monkeypatch.setattr(ops, "BF16_STORAGE", storage)
+        for p in m.parameters():
+            p.grad = None
+        dx, dy = m(x, sigma)
+        ((dx * gx).sum() + (dy * gx).sum()).backward()
+        return dx.detach(), dy.detach(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    on, off = run(True), run(False)
+    assert torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])
+    assert len(on[2]) == len(off[2]) > 50
+    for u, v in zip(on[2], off[2]):
+        assert float((u - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-3)
