@@ -13,18 +13,21 @@
 // ds_read_b64_tr_b16 (a 16-lane group gets 4 tiles x 16 channels column-major: lane i receives channel i of four consecutive
 // tiles, exactly the k-run a 32x32x16 operand lane needs; tools/tr_probe.hip).
 //
-// Wave-specialised like conv_wino2d_x6.hip (512 threads, one workgroup per CU):
-//   * waves 4-7 PRODUCE both operands: thread = (tile of the stage, 16-byte channel quad), a wave covers 4 tiles x 64 channels = four
-//     whole 256-byte runs per load instruction; loads of a stage (<= 4 of dY, 8 of X) are issued three stages ahead into one of three
-//     register sets; y combination, x transform (f32), three-term split, 24 ds_write_b64 per stage;
-//   * waves 0-3 CONSUME: 32 couts x 32 cins x 4 ex each; per stage 48 transposed fragment reads and 24 MFMAs.  The MFMA accumulators
-//     run over four stages (<= 24 matrix adds from C = 0) and are then added to the running totals with f32 adds (the long sums see
-//     rounded f32 adds, not truncating matrix adds);
+// Wave-specialised like conv_wino2d_x6.hip (768 threads = twelve waves, one workgroup per CU):
+//   * waves 4-7 PRODUCE the dY-side operand, waves 8-11 the X-side operand: thread = (tile of the stage, 16-byte channel quad), a wave
+//     covers 4 tiles x 64 channels = four whole 256-byte runs per load instruction; loads of a stage (<= 4 of dY / 8 of X) are issued
+//     three stages ahead into one of three register sets; y combination, x transform (f32), three-term split, 12 ds_write_b64 per stage;
+//   * waves 0-3 CONSUME: 32 couts x 32 cins x 4 ex each; per stage 48 transposed fragment reads and 24 MFMAs: six products per ex plane
+//     from C = 0, then one rounded f32 add into the running totals (the long sums see rounded f32 adds, not truncating matrix adds);
 //   * one s_barrier per stage with LDS-only counters: the producers' loads stay in flight across it.
 // Replaces the autograd weight gradient of Conv2d.forward (/root/reference/unet/uncond_unet.py:98-110).
 #include <algorithm>
 #include "common.h"
 #include "../../include/adm_hip.h"
+
+#ifndef XW_ABL
+#define XW_ABL 0      // diagnostic builds (tools/bench_wgrad_x6.cpp): 1 no global loads, 2 no transform / split / LDS stores, 8 no MFMAs, 16 no fragment reads
+#endif
 
 namespace {
 
@@ -43,7 +46,6 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int XT = 64, XK = 16;                    // 64 x 64 channel tile, 16 tiles (2x2 pixels each) per stage
 constexpr int XROW = 96;                           // bf16 elements per LDS row: 64 channels + 32 of padding (192 bytes)
 constexpr int X_IMG = 4 * 3 * XK * XROW;           // one operand image of a stage: [4 ex][3 terms][16 tiles][XROW] = 36 KB
-constexpr int X_FOLD = 4;                          // stages per accumulator run
 
 __device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
   f32x2 r;
@@ -70,6 +72,13 @@ __device__ __forceinline__ void split3x(const f32x4 v, u32x2& t0, u32x2& t1, u32
   t2 = u32x2{__builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u),
              __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u)};
 }
+// a + sgn b, sgn = +-1 uniform (exact; one packed fma per pair -- a uniform "add or subtract" written as a conditional costs a branch per use)
+__device__ __forceinline__ f32x4 fma4s(f32x4 a, f32x4 b, f32x2 sgn) {
+  f32x2 lo, hi;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(f32x2{b[0], b[1]}), "v"(sgn), "v"(f32x2{a[0], a[1]}));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(f32x2{b[2], b[3]}), "v"(sgn), "v"(f32x2{a[2], a[3]}));
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 __device__ __forceinline__ void store_planes(const f32x4 (&v)[4], unsigned short* l) {
 #pragma unroll
   for (int ex = 0; ex < 4; ++ex) {
@@ -90,11 +99,14 @@ __device__ __forceinline__ void lds_barrier() {    // waits for this wave's LDS 
 // images, reads and MFMAs with the four `ex` planes of a stage holding four consecutive 16-pixel chunks (64 pixels per stage, no
 // transforms, gridDim.y = 1); the epilogue adds the four accumulators.
 template <int MODE>
-__global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
+__global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smx[];
   unsigned short* As = smx;                        // [2][X_IMG]  dY side: rows = tiles, columns = couts
   unsigned short* Bs = smx + 2 * X_IMG;            // [2][X_IMG]  X side:  rows = tiles, columns = cins
   const int tid = threadIdx.x, lane = tid & 63, hw_wid = tid >> 6;
+  // twelve waves, three per SIMD: 0-3 consume, 4-7 produce the dY-side operand, 8-11 the X-side operand.  With both operands on
+  // ONE producer group the kernel was producer-bound (ablation: producers alone 0.373 of 0.448 ms, consumers alone 0.183), and a
+  // producer wave is latency-bound, not VALU-throughput-bound (its ~200 instructions per stage use 22 % of the SIMD's issue slots)
   const bool producer = hw_wid >= 4;
   const int wid = hw_wid & 3;
   const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
@@ -110,8 +122,13 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
   if (MODE == 0 && p.up && ey == 2) KT = 0;
   constexpr unsigned OOB = 0x80000000u;
 
+  // VALU work and the bf16 MFMA of different waves of one SIMD do not overlap (tools/overlap_probe.hip: the two times add), so a SIMD's
+  // stage is its MFMA time PLUS its producers' VALU time; producers first (measured: 0.401 -> 0.379 ms; consumers first: no change)
+  if (producer) __builtin_amdgcn_s_setprio(3);
   if (producer) {
-    // ================================================================ both operands
+    // ================================================================ one operand per producer group (side is compile-time)
+    auto produce = [&](auto side_c) {
+    constexpr bool x_side = decltype(side_c)::value;
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
     const int tl = wid * 4 + (lane >> 4), quad = lane & 15;       // tile of the stage, channel quad
@@ -121,17 +138,25 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
     const unsigned ystep = (unsigned)p.lddy * 4u, yrow = (unsigned)p.W * ystep;
     const unsigned xstep = (unsigned)p.ldx * 4u;
     const int iA = (ey == 0) ? 0 : 1, iB = (ey == 3) ? 3 : 2;       // X rows of this pass: (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey]
+    // y combination of this pass as a + sgn b: dY rows (r0, r0 + r1, r0 - r1, -r1)[ey], X rows (r0 - r2, r1 + r2, -(r2 - r1), r1 - r3)[ey]
+    const float sg = x_side ? (ey == 1 ? 1.f : -1.f) : (ey <= 1 ? 1.f : -1.f);
+    const f32x2 sgn = {sg, sg};
     constexpr int D = 3;                           // stages in flight
-    f32x4 t0[D][2], t1[D][2], u0[D][4], u1[D][4];
+    f32x4 u0[D][4], u1[D][4];                      // dY side: u0 = (r0 px0, r0 px1, r1 px0, r1 px1); X side: u0 / u1 = rows iA / iB
     auto issue = [&](int d, int s) {               // loads of stage s -> register set d (stages past the end read nothing)
-      if (MODE == 1) {                             // chunk xi of the stage: pixel pbeg + 64 s + 16 xi + tl, one quad of dY and of X
+      if (MODE == 1) {                             // chunk xi of the stage: pixel pbeg + 64 s + 16 xi + tl, one quad of dY or of X
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
           const int px = pbeg + s * STEP + xi * XK + tl;
           const bool pv = px < pend && s < KT;
-          u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)((pv && a_col != OOB) ? (unsigned)px * ystep + a_col : OOB), 0, 0));
-          u1[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((pv && b_col != OOB) ? (unsigned)px * xstep + b_col : OOB), 0, 0));
+          if (!x_side) u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)((pv && a_col != OOB) ? (unsigned)px * ystep + a_col : OOB), 0, 0));
+          else u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((pv && b_col != OOB) ? (unsigned)px * xstep + b_col : OOB), 0, 0));
         }
+        return;
+      }
+      if (XW_ABL & 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { u0[d][j] = f32x4{1.f, 2.f, (float)s, (float)j}; u1[d][j] = f32x4{0.5f, 0.25f, (float)j, 1.f}; }
         return;
       }
       const int pr = pbeg + s * XK + tl;
@@ -139,12 +164,15 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
       const int xp = pr & (Wh - 1), ty = (pr >> lwh) & (Hh - 1);
       const unsigned pix = ((unsigned)(pr >> lwh) << (p.lw + 1)) + 2u * (unsigned)xp;      // top-left output pixel of the tile
       // dY rows 2ty (r0) and 2ty + 1 (r1): a_y = (r0, r0 + r1, r0 - r1, -r1)[ey]; a row the pass does not use is read out of range
-      const unsigned ya = (pv && a_col != OOB) ? pix * ystep + a_col : OOB;
-      const unsigned y0 = (ey != 3) ? ya : OOB, y1 = (ey != 0 && ya != OOB) ? ya + yrow : OOB;
-      t0[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y0, 0, 0));
-      t0[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y0 != OOB ? y0 + ystep : OOB), 0, 0));
-      t1[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y1, 0, 0));
-      t1[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y1 != OOB ? y1 + ystep : OOB), 0, 0));
+      if (!x_side) {
+        const unsigned ya = (pv && a_col != OOB) ? pix * ystep + a_col : OOB;
+        const unsigned y0 = (ey != 3) ? ya : OOB, y1 = (ey != 0 && ya != OOB) ? ya + yrow : OOB;
+        u0[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y0, 0, 0));
+        u0[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y0 != OOB ? y0 + ystep : OOB), 0, 0));
+        u0[d][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y1, 0, 0));
+        u0[d][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y1 != OOB ? y1 + ystep : OOB), 0, 0));
+        return;
+      }
       const bool vA = pv && b_col != OOB && (iA != 0 || ty > 0), vB = pv && b_col != OOB && (iB != 3 || ty < Hh - 1);
       // up-sampled: the tile's source pixel is pixel `pr` of the half-resolution image; up-sampled row 2ty - 1 + i reads source row
       // ty + (i + 1) / 2 - 1 (columns likewise)
@@ -161,27 +189,30 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
       }
     };
     // the bias gradient = sum of every dY pixel = the ex = 1 component (e0 + e1 along x) of the ey = 1 workgroups (r0 + r1 along y)
-    const bool do_bias = p.dbias != nullptr && tn == 0 && ey == (MODE == 1 ? 0 : 1);
+    const bool bias_wg = p.dbias != nullptr && tn == 0 && ey == (MODE == 1 ? 0 : 1);     // (workgroup-uniform)
+    const bool do_bias = bias_wg && !x_side;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     unsigned short* la = As + tl * XROW + quad * 4;
     unsigned short* lb = Bs + tl * XROW + quad * 4;
     auto store = [&](int d, int slot) {            // y combination, x transforms, split, into slot
+      if (XW_ABL & 2) return;
       if (MODE == 1) {
         if (do_bias) bsum += (u0[d][0] + u0[d][1]) + (u0[d][2] + u0[d][3]);
-        store_planes(u0[d], la + slot * X_IMG);
-        store_planes(u1[d], lb + slot * X_IMG);
+        store_planes(u0[d], (x_side ? lb : la) + slot * X_IMG);
         return;
       }
-      f32x4 e[2], dd[4];
-      if (ey <= 1) { e[0] = t0[d][0] + t1[d][0]; e[1] = t0[d][1] + t1[d][1]; }     // the unused row was read as zeros
-      else { e[0] = sub4x(t0[d][0], t1[d][0]); e[1] = sub4x(t0[d][1], t1[d][1]); }
+      if (!x_side) {
+        const f32x4 e[2] = {fma4s(u0[d][0], u0[d][2], sgn), fma4s(u0[d][1], u0[d][3], sgn)};     // r0 +- r1 (an unused row was read as zeros)
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 a[4] = {e[0], e[0] + e[1], sub4x(e[0], e[1]), sub4x(zero, e[1])};
+        if (do_bias) bsum += a[1];
+        store_planes(a, la + slot * X_IMG);
+        return;
+      }
+      f32x4 dd[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dd[j] = (ey == 1) ? u0[d][j] + u1[d][j] : (ey == 2) ? sub4x(u1[d][j], u0[d][j]) : sub4x(u0[d][j], u1[d][j]);
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 a[4] = {e[0], e[0] + e[1], sub4x(e[0], e[1]), sub4x(zero, e[1])};
+      for (int j = 0; j < 4; ++j) dd[j] = fma4s(u0[d][j], u1[d][j], sgn);     // rows iA +- iB; the pass ey = 2 wants iB - iA: the epilogue negates
       const f32x4 b[4] = {sub4x(dd[0], dd[2]), dd[1] + dd[2], sub4x(dd[2], dd[1]), sub4x(dd[1], dd[3])};
-      if (do_bias) bsum += a[1];
-      store_planes(a, la + slot * X_IMG);
       store_planes(b, lb + slot * X_IMG);
     };
 #pragma unroll
@@ -200,14 +231,14 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
         }
       }
     }
-    if (do_bias) {     // lanes l, l + 16, l + 32, l + 48 of a wave hold four tiles of the same channel quad; four producer waves
+    if (bias_wg) {     // lanes l, l + 16, l + 32, l + 48 of a wave hold four tiles of the same channel quad; four dY-side waves
 #pragma unroll
       for (int j = 0; j < 4; ++j) { bsum[j] += __shfl_xor(bsum[j], 16, 64); bsum[j] += __shfl_xor(bsum[j], 32, 64); }
       float* red = reinterpret_cast<float*>(smx);  // every image has been consumed: the consumers are past the last barrier ...
-      lds_barrier();                               // ... once they arrive here (they make the same two extra barriers)
-      if (lane < 16) *reinterpret_cast<f32x4*>(red + (wid * 16 + lane) * 4) = bsum;
+      lds_barrier();                               // ... once they arrive here (all twelve waves make the same two extra barriers)
+      if (do_bias && lane < 16) *reinterpret_cast<f32x4*>(red + (wid * 16 + lane) * 4) = bsum;
       lds_barrier();
-      if (wid == 0 && lane < 16 && a_col != OOB) {
+      if (do_bias && wid == 0 && lane < 16 && a_col != OOB) {
         f32x4 v = *reinterpret_cast<const f32x4*>(red + lane * 4);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * 16 + lane) * 4);
@@ -218,79 +249,102 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WxP p) {
         }
       }
     }
+    };
+    if (hw_wid >= 8) produce(std::true_type{});
+    else produce(std::false_type{});
+    lds_barrier();                                 // the consumers' plane exchange (two barriers for all twelve waves)
+    lds_barrier();
     return;
   }
 
   // ================================================================== consumer waves
-  const int wm = wid >> 1, wn = wid & 1;           // 32-cout block, 32-cin block
+  // wave w owns the ex = w plane (MODE 1: pixel chunk w) of the whole 64 x 64 tile: 2 x 2 blocks of 32 x 32, so every fragment it
+  // reads feeds two block products (12 KB of LDS reads per stage and wave; 32 x 32 x 4 planes per wave read 24 KB)
   // transposed fragment read: 16-lane group g, lane i = 4 q + p of it: row (tile) 8 (g >> 1) + q [+ 4 for the second read],
-  // columns 16 (g & 1) + 4 p .. + 3 of the wave's 32-channel block; the lane receives channel 16 (g & 1) + i of those four tiles
+  // columns 16 (g & 1) + 4 p .. + 3 of a 32-channel block; the lane receives channel 16 (g & 1) + i of those four tiles
   const int g = lane >> 4, gi = lane & 15;
-  const int fr = (8 * (g >> 1) + (gi >> 2)) * XROW + 16 * (g & 1) + 4 * (gi & 3);
-  const int a_foff = fr + wm * 32, b_foff = fr + wn * 32;
-  f32x16 acc[4], tot[4];
+  const int foff = (8 * (g >> 1) + (gi >> 2)) * XROW + 16 * (g & 1) + 4 * (gi & 3) + wid * 3 * XK * XROW;
+  f32x16 tot[2][2];
 #pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tot[xi][r] = 0.f;
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 16; ++r) tot[i >> 1][i & 1][r] = 0.f;
   auto frag = [&](const unsigned short* base) -> bf16x8 {
     struct { s16x4 lo, hi; } v;
     v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
     v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * XROW));
     return __builtin_bit_cast(bf16x8, v);
   };
-  int run = 0;
   for (int s = 0; s < KT; ++s) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const unsigned short* Ab = As + (s & 1) * X_IMG + a_foff;
-    const unsigned short* Bb = Bs + (s & 1) * X_IMG + b_foff;
-    const bool first = run == 0;
+    const unsigned short* Ab = As + (s & 1) * X_IMG + foff;
+    const unsigned short* Bb = Bs + (s & 1) * X_IMG + foff;
+    bf16x8 a[2][3], b[2][3];
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi) {
-      bf16x8 a[3], b[3];
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        a[k] = frag(Ab + (xi * 3 + k) * XK * XROW);
-        b[k] = frag(Bb + (xi * 3 + k) * XK * XROW);
+        if (XW_ABL & 16) {
+          struct { s16x4 lo, hi; } fk = {{(short)0x3f80, (short)s, (short)0x3f80, (short)h}, {(short)0x3f00, (short)k, (short)0x3f00, (short)lane}};
+          a[h][k] = __builtin_bit_cast(bf16x8, fk); b[h][k] = a[h][k];
+          continue;
+        }
+        a[h][k] = frag(Ab + k * XK * XROW + h * 32);
+        b[h][k] = frag(Bb + k * XK * XROW + h * 32);
       }
-      f32x16 c;
-      if (first) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], zero, 0, 0, 0);       // (wave-uniform branch)
-      else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[xi], 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-    }
-    if (++run == X_FOLD || s + 1 == KT) {
-      run = 0;
 #pragma unroll
-      for (int xi = 0; xi < 4; ++xi) tot[xi] += acc[xi];
-    }
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        if (XW_ABL & 8) { tot[mb][nb][0] += (float)(__builtin_bit_cast(s16x4, __builtin_bit_cast(u32x2, *(u32x2*)&a[mb][0]))[0] ^ __builtin_bit_cast(s16x4, *(u32x2*)&b[nb][2])[1]); continue; }
+        // six products of this stage from C = 0 (small ones first), then ONE rounded f32 add into the running total
+        f32x16 c;                                  // C = the inline constant 0 (the builtin with a zero vector first copies sixteen zeros)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a[mb][0]), "v"(b[nb][2]));
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][2], b[nb][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][1], b[nb][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][0], b[nb][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][1], b[nb][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][0], b[nb][0], c, 0, 0, 0);
+        tot[mb][nb] += c;
+      }
   }
   if (p.dbias != nullptr && tn == 0 && ey == (MODE == 1 ? 0 : 1)) {  // the producers' bias reduction uses two more barriers
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
   }
 
-  // ---- epilogue: G^T along x.  C/D layout: col = lane & 31 (cin), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (cout)
-  const int lr = lane & 31, lh = lane >> 5;
-  const int ci = ci0 + wn * 32 + lr;
-  if (ci >= p.Cin) return;
-  const int cb = co0 + wm * 32 + 4 * lh;
+  // ---- epilogue: the four planes meet in LDS ([plane][cout 64][cin 64] f32 = 64 KB; all twelve waves make these two barriers), then
+  // G^T along x.  C/D layout: col = lane & 31 (cin), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (cout)
+  float* ex_t = reinterpret_cast<float*>(smx);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the images (and the bias scratch)
+  {
+    const int lr = lane & 31, lh = lane >> 5;
+    const float osgn = (MODE == 0 && ey == 2) ? -1.f : 1.f;      // the X side of the pass ey = 2 was produced negated
 #pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ex_t[(wid * XT + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XT + nb * 32 + lr] = osgn * tot[mb][nb][r];
+  }
+  lds_barrier();
+  const int ci = ci0 + lane;                       // wave w: couts 16 w .. 16 w + 15 of the tile, lane = cin (256-byte rows)
+  if (ci >= p.Cin) return;
+#pragma unroll 4
   for (int r = 0; r < 16; ++r) {
-    const int co = cb + (r & 3) + 8 * (r >> 2);
-    if (co >= p.Cout) continue;
+    const int cr = wid * 16 + r, co = co0 + cr;
+    if (co >= p.Cout) break;
+    const float t0 = ex_t[(0 * XT + cr) * XT + lane], t1 = ex_t[(1 * XT + cr) * XT + lane];
+    const float t2 = ex_t[(2 * XT + cr) * XT + lane], t3 = ex_t[(3 * XT + cr) * XT + lane];
     if (MODE == 1) {
-      const float w = (tot[0][r] + tot[1][r]) + (tot[2][r] + tot[3][r]);
+      const float w = (t0 + t1) + (t2 + t3);
       float* dst1 = p.dwp + (long)blockIdx.z * p.split_stride + (long)co * p.Cin + ci;
       if (p.atomic) atomicAdd(dst1, w); else dst1[0] = w;
       continue;
     }
-    const float h = 0.5f * (tot[1][r] + tot[2][r]);
-    const float w0 = tot[0][r] + h, w1 = 0.5f * (tot[1][r] - tot[2][r]), w2 = h + tot[3][r];
+    const float h = 0.5f * (t1 + t2);
+    const float w0 = t0 + h, w1 = 0.5f * (t1 - t2), w2 = h + t3;
     float* dst = p.dwp + (long)blockIdx.z * p.split_stride + ((long)co * 12 + ey * 3) * p.Cin + ci;
     if (p.atomic) {
       atomicAdd(dst, w0); atomicAdd(dst + p.Cin, w1); atomicAdd(dst + 2 * p.Cin, w2);
@@ -358,7 +412,7 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
     attr_set = true;
   }
   dim3 grid(adm_cdiv(Cout, XT) * p.tilesN, 4, splits);
-  hipLaunchKernelGGL(wgrad_x6_kernel<0>, grid, dim3(512), smem, stream, p);
+  hipLaunchKernelGGL(wgrad_x6_kernel<0>, grid, dim3(768), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -406,7 +460,7 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
     attr_set = true;
   }
   dim3 grid(adm_cdiv(Cout, XT) * p.tilesN, 1, splits);
-  hipLaunchKernelGGL(wgrad_x6_kernel<1>, grid, dim3(512), smem, stream, p);
+  hipLaunchKernelGGL(wgrad_x6_kernel<1>, grid, dim3(768), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -1,7 +1,6 @@
 // Diagnostic micro-benchmark / check of the split-bf16 2-D Winograd weight gradient against the f32-MFMA kernel (not part of the product).
 // hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/bench_wgrad_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bwx && LD_LIBRARY_PATH=adm_amd /tmp/bwx
-#include "../include/adm_hip.h"
-#include <hip/hip_runtime.h>
+#include "../adm_amd/csrc/conv_wgrad_x6.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -45,6 +44,9 @@ static void run(int B, int H, int Cin, int Cout) {
   hipFree(x); hipFree(dy); hipFree(w0); hipFree(w1); hipFree(b0); hipFree(b1);
 }
 int main() {
+#if XW_ABL
+  printf("ABL=%d ", XW_ABL); run(128, 32, 192, 192); return 0;
+#endif
   run(2, 8, 32, 64);
   run(8, 16, 96, 64);
   run(128, 32, 192, 192);
