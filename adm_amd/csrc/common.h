@@ -6,6 +6,10 @@
 #define ADM_OK 0
 #define ADM_EINVAL (-22)
 #define ADM_ELAUNCH (-5)
+// `splits` of the atomic weight-gradient entry points: 0 = chosen by the launcher (the workspace is cleared first);
+// -1 = chosen by the launcher, the caller GUARANTEES the workspace is all zero on entry (zero-at-rest: adm_unpack_wgrad_table
+// clears what it reads), so no memset is enqueued
+#define ADM_SPLITS_AUTO_PREZEROED (-1)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

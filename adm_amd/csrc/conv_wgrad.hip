@@ -280,6 +280,7 @@ int wgrad_impl(const float* x, const float* dy, float* dwp, float* dbias, int B,
   // 128 x 128 one) instead of 64-row tiles, which halve the operand reuse
   const int TM = (Cout % 128 == 0) ? 128 : (Cout % 192 == 0) ? 192 : 64;
   const int TN = (TM == 192) ? 64 : (Cin % 128 == 0) ? 128 : 64;
+  const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;      // zero-at-rest workspace: no memset
   if (splits <= 0) {
     // Fill the resident slots (256 CUs x 2 workgroups, 4 for the 64x64 tile) in WHOLE rounds: tiles * splits must
     // not exceed a multiple of the slot count by a few workgroups (a 513th workgroup costs a full extra round).
@@ -299,7 +300,7 @@ int wgrad_impl(const float* x, const float* dy, float* dwp, float* dbias, int B,
   if (plan_only) return splits;
   p.chunk = chunk;
   p.atomic = splits > 1 && split_stride == 0;
-  if (p.atomic &&
+  if (p.atomic && !prezeroed &&
       hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * ks * ks * Cin, stream) != hipSuccess)
     return ADM_ELAUNCH;
   if (TM == 192) return launch_wgrad<192, 64>(p, splits, stream);

@@ -255,6 +255,7 @@ static int conv_wgrad_bf16_impl(const float* x, const float* dy, float* dwp, int
   if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
   const int TM = (Cout % 128 == 0) ? 128 : 64;
   const int TN = (Cin % 128 == 0) ? 128 : 64;
+  const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;      // zero-at-rest workspace: no memset
   if (splits <= 0) {
     const long tiles = (long)adm_cdiv(Cout, TM) * adm_cdiv(Cin, TN) * ks * ks;
     const long slots = 256L * 2;
@@ -270,7 +271,7 @@ static int conv_wgrad_bf16_impl(const float* x, const float* dy, float* dwp, int
   splits = (p.P + chunk - 1) / chunk;
   p.chunk = chunk;
   p.atomic = splits > 1;
-  if (p.atomic &&
+  if (p.atomic && !prezeroed &&
       hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * ks * ks * Cin, stream) != hipSuccess)
     return ADM_ELAUNCH;
   if (TM == 128 && TN == 128) return launch_wb<128, 128>(p, splits, stream);

@@ -263,6 +263,7 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
   p.tilesN = adm_cdiv(Cin, WT);
   const int gy = twod ? 4 : 3;
   const long tiles = (long)adm_cdiv(Cout, WT) * p.tilesN * gy;
+  const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;      // zero-at-rest workspace: no memset
   if (splits <= 0) {
     // 768 resident slots (3 workgroups per CU).  Pick the split count whose workgroup total fills whole rounds best
     // (tiles * s close below a multiple of 768), with a mild preference for fewer splits (atomics, shorter K loops);
@@ -285,7 +286,7 @@ int wgrad_wino_impl(const float* x, const float* dy, float* dwp, float* dbias, i
   p.split_stride = det ? (long)Cout * p.taps * Cin : 0;
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
-  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * p.taps * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
+  if (p.atomic && !prezeroed && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * p.taps * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
   constexpr int smem = 4 * (WT + WT) * WKK * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

@@ -381,6 +381,7 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, XT);
   const long tiles = (long)adm_cdiv(Cout, XT) * p.tilesN * 4;
+  const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;      // zero-at-rest workspace: no memset
   if (splits <= 0) {
     // one workgroup per CU: 256 slots.  The split count whose workgroup total fills whole rounds best, with a mild preference for
     // fewer splits; >= 96 tiles (6 stages) per split
@@ -402,7 +403,7 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   p.split_stride = det ? (long)Cout * 12 * Cin : 0;
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
-  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 12 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
+  if (p.atomic && !prezeroed && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 12 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
   constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
@@ -431,6 +432,7 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
   p.tilesN = adm_cdiv(Cin, XT);
   const long tiles = (long)adm_cdiv(Cout, XT) * p.tilesN;
   constexpr int STEP = 4 * XK;
+  const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;
   if (splits <= 0) {        // whole rounds of 256 workgroups (one per CU); >= 6 stages (384 pixels) per split
     const long slots = 256;
     const int maxs = (int)std::min<long>((P + 6 * STEP - 1) / (6 * STEP), 128);
@@ -450,7 +452,7 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
   p.split_stride = det ? (long)Cout * Cin : 0;
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
-  if (p.atomic && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
+  if (p.atomic && !prezeroed && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
   constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {

@@ -403,3 +403,62 @@ extern "C" int adm_unpack_wgrad_wino2d(const float* wx, int splits, float* dw, i
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
+
+namespace {
+// One launch for the weight gradients of ALL layers.  Row = 12 int64: {src, dst, Co, Ci, taps (0: 2-D Winograd planes), Ci_pad, qkv,
+// accumulate, zero_src, block_begin, 0, 0}; block_begin = exclusive prefix sum of the rows' block counts (UT_ITEMS items per block;
+// items = Co*Ci*taps, or Co*Ci*3 for the Winograd planes, as in unpack_kernel / unpack_wino2d_kernel).
+constexpr int UT_ITEMS = 2048, UT_COLS = 12;
+__global__ __launch_bounds__(256) void unpack_table_kernel(const long* __restrict__ table, int rows) {
+  int lo = 0, hi = rows - 1;                        // last row whose block_begin <= blockIdx.x (uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(long)mid * UT_COLS + 9] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long* r = table + (long)lo * UT_COLS;
+  float* src = reinterpret_cast<float*>(r[0]);
+  float* dw = reinterpret_cast<float*>(r[1]);
+  const int Co = (int)r[2], Ci = (int)r[3], taps = (int)r[4], Ci_pad = (int)r[5], qkv = (int)r[6];
+  const bool accumulate = r[7] != 0, zero = r[8] != 0;
+  const long b0 = ((long)blockIdx.x - r[9]) * UT_ITEMS;
+  if (taps > 0) {
+    const long total = (long)Co * Ci * taps;
+    for (long idx = b0 + threadIdx.x; idx < min(total, b0 + UT_ITEMS); idx += 256) {
+      const int tap = idx % taps;
+      const long t = idx / taps;
+      const int ci = t % Ci, co = t / Ci;
+      const int cop = qkv ? qkv_to_packed(co) : co;
+      float* sp = src + ((long)cop * taps + tap) * Ci_pad + ci;
+      const float v = *sp;
+      if (zero) *sp = 0.f;
+      dw[idx] = accumulate ? dw[idx] + v : v;
+    }
+  } else {
+    const long total = (long)Co * Ci * 3;
+    for (long idx = b0 + threadIdx.x; idx < min(total, b0 + UT_ITEMS); idx += 256) {
+      const int kx = idx % 3;
+      const long t = idx / 3;
+      const int ci = t % Ci, co = t / Ci;
+      float m[4];
+#pragma unroll
+      for (int ey = 0; ey < 4; ++ey) {
+        float* sp = src + (((long)co * 4 + ey) * 3 + kx) * Ci_pad + ci;
+        m[ey] = *sp;
+        if (zero) *sp = 0.f;
+      }
+      const float h = 0.5f * (m[1] + m[2]);
+      const float w[3] = {m[0] + h, 0.5f * (m[1] - m[2]), h + m[3]};
+      float* o = dw + ((long)co * Ci + ci) * 9 + kx;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) o[ky * 3] = accumulate ? o[ky * 3] + w[ky] : w[ky];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int adm_unpack_wgrad_table(const long* table, int rows, long total_blocks, hipStream_t stream) {
+  if (!table || rows <= 0 || total_blocks <= 0 || total_blocks >= (1L << 31)) return ADM_EINVAL;
+  hipLaunchKernelGGL(unpack_table_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, table, rows);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}

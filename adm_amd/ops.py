@@ -288,6 +288,74 @@ def repack_all():
 
 
 # ------------------------------------------------------------------------------------------------
+# deferred weight-gradient unpack (launches per step)
+# ------------------------------------------------------------------------------------------------
+# The weight-gradient kernels leave a packed (and, for the 2-D Winograd form, half-transformed) tile per layer; a small "unpack"
+# launch per layer used to scatter it into the flat gradient buffer, and a memset per layer cleared the tile before the split-K
+# atomics.  With direct gradients (adm_amd.optim.FlatParams) both go away: every layer owns a persistent workspace that is ZERO AT
+# REST, the kernels are told so (splits = -1: no memset), and ONE adm_unpack_wgrad_table launch at the end of the backward pass
+# scatters all layers and clears what it read.  A gradient sink (the bucketed DDP reducer) needs the gradient when it is
+# notified, so any notification flushes first.  ADM_DEFER_UNPACK=0 restores the per-layer launches.
+DEFER_UNPACK = os.environ.get("ADM_DEFER_UNPACK", "1") != "0"
+_rest_ws = {}               # (weight data_ptr, numel) -> zero-at-rest workspace
+_unpack_rows = []           # pending rows of the table (host ints) + the tensors they point into
+_unpack_keep = []
+_unpack_table = None        # (key tuple, device table, total blocks)
+_unpack_queued = False
+_UT_ITEMS = 2048
+
+
+def _rest_workspace(weight, shape, like):
+    key = (weight.data_ptr(), shape)
+    ws = _rest_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(shape, device=like.device, dtype=_f32)
+        _rest_ws[key] = ws
+    return ws
+
+
+def _defer_unpack(ws, dst, co, ci, taps, cip, qkv):
+    """Queue `dst (OIHW) += unpack(ws)` for the end-of-backward table launch; taps = 0 for the 2-D Winograd planes."""
+    global _unpack_queued
+    items = co * ci * (taps if taps else 3)
+    _unpack_rows.append((ws.data_ptr(), dst.data_ptr(), co, ci, taps, cip, int(qkv), 1, 1, (items + _UT_ITEMS - 1) // _UT_ITEMS))
+    _unpack_keep.append((ws, dst))
+    if not _unpack_queued:
+        _unpack_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
+
+
+def flush_deferred_unpack():
+    """Scatter every pending weight-gradient workspace into its gradient (one launch) and clear the workspaces."""
+    global _unpack_table, _unpack_queued
+    _unpack_queued = False
+    if not _unpack_rows:
+        return
+    key = tuple(_unpack_rows)
+    if _unpack_table is None or _unpack_table[0] != key:
+        rows, begin = [], 0
+        for r in _unpack_rows:
+            rows.append(list(r[:9]) + [begin, 0, 0])
+            begin += r[9]
+        _unpack_table = (key, torch.tensor(rows, dtype=torch.int64, device=_unpack_keep[0][0].device), begin)
+    _, table, blocks = _unpack_table
+    n = len(_unpack_rows)
+    _unpack_rows.clear()
+    _unpack_keep.clear()
+    call("adm_unpack_wgrad_table", ptr(table), n, blocks)
+
+
+def reset_deferred_unpack():
+    """Drop pending rows and re-zero every workspace (after a backward pass that raised half-way)."""
+    global _unpack_queued
+    _unpack_queued = False
+    _unpack_rows.clear()
+    _unpack_keep.clear()
+    for ws in _rest_ws.values():
+        ws.zero_()
+
+
+# ------------------------------------------------------------------------------------------------
 # direct gradient accumulation
 # ------------------------------------------------------------------------------------------------
 # adm_amd.optim.FlatParams marks parameters whose .grad is a view into the flat gradient buffer
@@ -304,6 +372,7 @@ def _direct_grad(param):
 def _notify(param):
     sink = getattr(param, "_adm_grad_sink", None)
     if sink is not None:
+        flush_deferred_unpack()       # the sink reads the gradient now
         sink(param)
 
 
@@ -469,6 +538,7 @@ class _Conv(torch.autograd.Function):
                 wmode = 2 if wino2_w else int(wino_w)
                 planes = 12 if wino2_w else ks * ks
                 det = DETERMINISTIC and not bf16
+                defer = DEFER_UNPACK and wsink is not None and not det and side is None
                 x6_w = wino2_w and BF16X6          # f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip)
                 g6_w = GEMM_WGRAD_X6 and BF16X6 and not bf16 and ks == 1 and not up and B * Ho * Wo >= GEMM_X6_MIN_M      # ... 1x1 convs (its MODE 1)
                 splits = 1
@@ -480,18 +550,21 @@ class _Conv(torch.autograd.Function):
                         raise RuntimeError(f"adm_conv_wgrad_plan failed with code {splits}")
                     dwp = _new((splits, cop, planes * cip), dy)
                     bws = _new((splits, cop), dy) if dbp is not None else None
+                elif defer:
+                    dwp = _rest_workspace(weight, (cop, planes * cip), dy)
                 else:
                     dwp = _new((cop, planes * cip), dy)
+                auto = -1 if defer else 0        # -1: chosen by the launcher, workspace zero on entry (no memset)
                 kind = "wgrad_wino2x6" if x6_w else "wgrad_gemmx6" if g6_w else "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
                 with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"{kind.replace('_', '-')} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16:
                         call("adm_conv_wgrad_bf16a" if x.dtype == torch.bfloat16 else "adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho,
-                             Wo, cip, cip, cop, cop, ks, int(up), 0)
+                             Wo, cip, cip, cop, cop, ks, int(up), auto)
                     elif det and g6_w:
                         call("adm_gemm_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B * Ho * Wo, cip, cip, cop, cop, splits)
                     elif g6_w:
-                        call("adm_gemm_wgrad_x6", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B * Ho * Wo, cip, cip, cop, cop, 0)
+                        call("adm_gemm_wgrad_x6", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B * Ho * Wo, cip, cip, cop, cop, auto)
                     elif det and x6_w:
                         call("adm_conv_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B, Ho, Wo, cip, cip, cop, cop, splits, int(up))
                     elif det:
@@ -499,21 +572,23 @@ class _Conv(torch.autograd.Function):
                              splits, wmode)
                     elif x6_w:
                         call("adm_conv_wgrad_x6_up" if up else "adm_conv_wgrad_x6", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip,
-                             cip, cop, cop, 0)
+                             cip, cop, cop, auto)
                     elif wino2_w:
-                        call("adm_conv_wgrad_wino2d", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, 0)
+                        call("adm_conv_wgrad_wino2d", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, auto)
                     elif wino_w:
                         call("adm_conv_wgrad_wino_up" if up else "adm_conv_wgrad_wino", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B,
-                             Ho, Wo, cip, cip, cop, cop, 0)
+                             Ho, Wo, cip, cip, cop, cop, auto)
                     else:
                         call("adm_conv_wgrad_bias", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, ks,
-                             int(up), 0)
+                             int(up), auto)
                 if wsink is not None:
                     dst, acc = wsink, 1
                 else:
                     dw = torch.empty_like(weight)
                     dst, acc = dw, 0
-                if wino2_w:      # the y half of G^T rides in the unpack: dW[ky] = sum_ey Gt[ky][ey] wx[ey]
+                if defer:
+                    _defer_unpack(dwp, dst, co, ci, 0 if wino2_w else ks * ks, cip, qkv)
+                elif wino2_w:    # the y half of G^T rides in the unpack: dW[ky] = sum_ey Gt[ky][ey] wx[ey]
                     call("adm_unpack_wgrad_wino2d", ptr(dwp), splits, ptr(dst), co, ci, cop, cip, acc, ptr(bws) if det else None,
                          ptr(dbp) if det else None)
                 elif det:

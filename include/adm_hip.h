@@ -205,6 +205,13 @@ int adm_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int ks, int Co
  * bws[splits][Co_pad] are summed into dbias[0..Co_pad) (+=, packed channel order); bws and dbias may both be NULL. */
 int adm_unpack_wgrad_splits(const float* ws, int splits, float* dw, int Co, int Ci, int ks, int Co_pad, int Ci_pad, int qkv,
                             int accumulate, const float* bws, float* dbias, hipStream_t stream);
+/* adm_unpack_wgrad / adm_unpack_wgrad_wino2d (splits = 1) for the weight gradients of ALL layers in ONE launch, issued once at the
+ * end of the backward pass.  table = device array of `rows` rows of 12 int64: {src, dst, Co, Ci, taps, Ci_pad, qkv, accumulate,
+ * zero_src, block_begin, 0, 0}; taps = ks*ks for the plain packed layout [Co_pad][taps][Ci_pad], 0 for the 2-D Winograd planes
+ * [Co_pad][4 ey][3 kx][Ci_pad]; a row owns ceil(items / 2048) blocks (items = Co*Ci*taps, or Co*Ci*3), block_begin = exclusive
+ * prefix sum, total_blocks = the sum.  zero_src != 0 clears every workspace element after reading it: with workspaces that are zero
+ * at rest the weight-gradient entry points take splits = -1 ("chosen by the launcher, workspace already zero") and enqueue no memset. */
+int adm_unpack_wgrad_table(const long* table, int rows, long total_blocks, hipStream_t stream);
 /* out[i] = in[perm(i)] over n_pad entries (zero beyond n); qkv permutation of bias vectors.
  * inverse=1 maps packed order back to the reference order. */
 int adm_permute_vec(const float* in, float* out, int n, int n_pad, int qkv, int inverse, hipStream_t stream);

@@ -156,3 +156,67 @@ def test_table_repack_equals_per_layer_pack():
             kinds.add("wino2d")
         kinds.add((ks, bool(qkv), cop != co, cip != ci))
     assert {(3, False, False, True), (3, False, True, False), (1, True, False, False), (1, False, False, False), "wino", "wino2d"} <= kinds
+
+
+def test_unpack_table_equals_per_layer_unpack_and_clears_the_workspaces():
+    """adm_unpack_wgrad_table (one launch for all layers, zero-at-rest workspaces) against adm_unpack_wgrad /
+    adm_unpack_wgrad_wino2d on the same packed tiles: bit-identical gradients, every element it read is cleared."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import hip
+    gpu = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    layers = [(64, 96, 9, 0), (192, 64, 1, 1), (40, 24, 1, 0), (96, 64, 0, 0), (33, 47, 9, 0), (64, 64, 0, 0)]   # (co, ci, taps | 0 = wino2d planes, qkv)
+    rows, keep, want, begin = [], [], [], 0
+    for co, ci, taps, qkv in layers:
+        cop, cip = (co + 31) // 32 * 32, (ci + 31) // 32 * 32
+        ws = torch.randn((cop, (taps if taps else 12) * cip), generator=g).to(gpu)
+        ks = 3 if taps in (0, 9) else 1
+        dst = torch.randn((co, ci, ks, ks), generator=g).to(gpu)
+        ref = dst.clone()
+        if taps:
+            hip.call("adm_unpack_wgrad", hip.ptr(ws), hip.ptr(ref), co, ci, ks, cop, cip, qkv, 1)
+        else:
+            hip.call("adm_unpack_wgrad_wino2d", hip.ptr(ws), 1, hip.ptr(ref), co, ci, cop, cip, 1, None, None)
+        items = co * ci * (taps if taps else 3)
+        rows.append([ws.data_ptr(), dst.data_ptr(), co, ci, taps, cip, qkv, 1, 1, begin, 0, 0])
+        begin += (items + 2047) // 2048
+        keep.append((ws, dst, cop, cip, co, ci, taps))
+        want.append(ref)
+    table = torch.tensor(rows, dtype=torch.int64, device=gpu)
+    hip.call("adm_unpack_wgrad_table", hip.ptr(table), len(rows), begin)
+    torch.cuda.synchronize()
+    for (ws, dst, cop, cip, co, ci, taps), ref in zip(keep, want):
+        assert torch.equal(dst, ref)
+        planes = ws.view(cop, taps if taps else 12, cip)
+        assert float(planes[:co, :, :ci].abs().max()) == 0.0      # (the qkv row's packed rows are a permutation of 0..co-1)
+
+
+def test_deferred_unpack_matches_per_layer_launches():
+    """A backward pass with the end-of-backward table unpack (default) against ADM_DEFER_UNPACK=0: same gradients (split-K
+    atomics reorder sums: 1e-5 relative), and every zero-at-rest workspace is zero again afterwards."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import ops
+    from adm_amd.optim import FlatParams
+    gpu = torch.device("cuda:0")
+    grads = []
+    old = ops.DEFER_UNPACK
+    try:
+        for defer in (False, True):
+            ops.DEFER_UNPACK = defer
+            m = _model(gpu)
+            flat = FlatParams(m)
+            for _ in range(2):
+                flat.zero_grad()
+                _loss(m, gpu).backward()
+            torch.cuda.synchronize()
+            grads.append(flat.grad.clone())
+            if defer:
+                assert ops._rest_ws and not ops._unpack_rows
+                for ws in ops._rest_ws.values():
+                    assert float(ws.abs().max()) == 0.0
+    finally:
+        ops.DEFER_UNPACK = old
+    scale = float(grads[0].abs().max())
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
