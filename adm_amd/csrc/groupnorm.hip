@@ -256,6 +256,41 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
   }
 }
 
+// gn_bwd_param_kernel for ALL GroupNorm layers of a backward pass in one launch.  Row = 8 int64: {tot, ss (0: none), ss_bstride,
+// dgamma, dbeta, B, C, block_begin}; a row owns ceil(C / 32) blocks, block_begin = exclusive prefix sum.  Same summation order.
+__global__ __launch_bounds__(256) void gn_bwd_param_table_kernel(const long* __restrict__ table, int rows) {
+  int lo = 0, hi = rows - 1;                        // last row whose block_begin <= blockIdx.x (uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(long)mid * 8 + 7] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long* r = table + (long)lo * 8;
+  const float* tot = reinterpret_cast<const float*>(r[0]);
+  const float* ss = reinterpret_cast<const float*>(r[1]);
+  const long ss_bstride = r[2];
+  float* dgamma = reinterpret_cast<float*>(r[3]);
+  float* dbeta = reinterpret_cast<float*>(r[4]);
+  const int B = (int)r[5], C = (int)r[6];
+  __shared__ float sa[8][32], sq[8][32];
+  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int c = ((int)((long)blockIdx.x - r[7])) * 32 + cl;
+  float a = 0.f, q = 0.f;
+  if (c < C)
+    for (int b = bl; b < B; b += 8) {
+      float sc1 = ss ? 1.f + ss[b * ss_bstride + c] : 1.f;
+      a += sc1 * tot[((long)b * C + c) * 2];
+      q += sc1 * tot[((long)b * C + c) * 2 + 1];
+    }
+  sa[bl][cl] = a; sq[bl][cl] = q;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { a += sa[k][cl]; q += sq[k][cl]; }
+    dbeta[c] += a;
+    dgamma[c] += q;
+  }
+}
+
 // pass 4: dx = rstd * (gamma' du - m1 - xhat m2)
 __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                  const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -688,6 +723,17 @@ extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stat
                        dbeta, B, C);
   hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(B, S), dim3(gn_threads(C)), 0, stream, x, dy, stats, gamma, beta, ss,
                      ss_bstride, gm, addend, dx, HW, C, G, rows, silu, drop_p, seed);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
+// The batch reduction of d(gamma) / d(beta) for every GroupNorm layer of a backward pass in ONE launch (adm_gn_bwd / adm_gn_bwd_add
+// called with dgamma = dbeta = NULL leave the per-image sums at red + adm_gn_bwd_tot_offset(...) floats; they must stay alive until
+// this runs).  table = device array of `rows` rows of 8 int64: {tot, ss (0: none), ss_bstride, dgamma, dbeta, B, C, block_begin};
+// a row owns ceil(C / 32) blocks; total_blocks = their sum.  dgamma / dbeta are accumulated (+=).
+extern "C" int adm_gn_bwd_param_table(const long* table, int rows, long total_blocks, hipStream_t stream) {
+  if (!table || rows <= 0 || total_blocks <= 0 || total_blocks >= (1L << 31)) return ADM_EINVAL;
+  hipLaunchKernelGGL(gn_bwd_param_table_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, table, rows);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -61,6 +61,7 @@ _SIGS = {
     "adm_pack_weight": [P, P, P, I, I, I, I, I, I, P],
     "adm_pack_weight_table": [P, I, L, P],
     "adm_unpack_wgrad_table": [P, I, L, P],
+    "adm_gn_bwd_param_table": [P, I, L, P],
     "adm_unpack_wgrad": [P, P, I, I, I, I, I, I, I, P],
     "adm_permute_vec": [P, P, I, I, I, I, P],
     "adm_colsum": [P, P, I, I, I, I, P],

@@ -325,10 +325,47 @@ def _defer_unpack(ws, dst, co, ci, taps, cip, qkv):
         torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
 
 
+_gn_rows = []               # pending GroupNorm parameter-gradient reductions: (tot, ss, bstride, dgamma, dbeta, B, C, blocks)
+_gn_keep = []
+_gn_table = None
+
+
+def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
+    """Queue `dgamma, dbeta += batch reduction of the per-image sums` for the end-of-backward table launch."""
+    global _unpack_queued
+    _gn_rows.append((red.data_ptr() + 4 * tot_off, 0 if ss is None else ss.data_ptr(), int(bstride), dgamma.data_ptr(),
+                     dbeta.data_ptr(), B, C, (C + 31) // 32))
+    _gn_keep.append((red, ss, dgamma, dbeta))
+    if not _unpack_queued:
+        _unpack_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
+
+
+def _flush_gn_params():
+    global _gn_table
+    if not _gn_rows:
+        return
+    # (the partial-sum buffers are fresh allocations, but the caching allocator hands out the same addresses every step: the device
+    #  table is re-uploaded -- a synchronising copy -- only when a row changed)
+    key = tuple(_gn_rows)
+    if _gn_table is None or _gn_table[0] != key:
+        rows, begin = [], 0
+        for r in _gn_rows:
+            rows.append(list(r[:7]) + [begin])
+            begin += r[7]
+        _gn_table = (key, torch.tensor(rows, dtype=torch.int64, device=_gn_keep[0][0].device), begin)
+    _, table, blocks = _gn_table
+    call("adm_gn_bwd_param_table", ptr(table), len(_gn_rows), blocks)
+    _gn_rows.clear()
+    _gn_keep.clear()
+
+
 def flush_deferred_unpack():
-    """Scatter every pending weight-gradient workspace into its gradient (one launch) and clear the workspaces."""
+    """Scatter every pending weight-gradient workspace into its gradient (one launch) and clear the workspaces; reduce the pending
+    GroupNorm parameter gradients (one launch)."""
     global _unpack_table, _unpack_queued
     _unpack_queued = False
+    _flush_gn_params()
     if not _unpack_rows:
         return
     key = tuple(_unpack_rows)
@@ -351,6 +388,8 @@ def reset_deferred_unpack():
     _unpack_queued = False
     _unpack_rows.clear()
     _unpack_keep.clear()
+    _gn_rows.clear()
+    _gn_keep.clear()
     for ws in _rest_ws.values():
         ws.zero_()
 
@@ -736,9 +775,13 @@ class _GroupNormAct(torch.autograd.Function):
         dgamma = sg if direct else torch.zeros_like(gamma)
         dbeta = sb if direct else torch.zeros_like(beta)
         red = _new((B * S * C * 2 + B * C * 2 + B * G * 2,), x)
+        defer = direct and DEFER_UNPACK and not DETERMINISTIC      # the batch reduction joins the end-of-backward table launch
         with _Prof("gn", (12.0 if add is None else 16.0) * x.numel(), f"gn-bwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)"):
             call("adm_gn_bwd_add", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
-                 ptr(add), ptr(dx), ptr(dss), ptr(dgamma), ptr(dbeta), ptr(red), B, HW, C, G, int(silu), float(drop_p), seed)
+                 ptr(add), ptr(dx), ptr(dss), None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(red), B, HW, C, G,
+                 int(silu), float(drop_p), seed)
+        if defer:
+            _defer_gn_param(red, B * S * C * 2, ss, bstride, dgamma, dbeta, B, C)
         if direct:
             _notify(gamma); _notify(beta)
             return dx, None, None, dss, None, None, None, None, None, None, None

@@ -246,6 +246,13 @@ int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float*
                const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta, float* red,
                int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);
 
+/* The batch reduction of dgamma / dbeta for EVERY GroupNorm layer of a backward pass in one launch: adm_gn_bwd / adm_gn_bwd_add
+ * called with dgamma = dbeta = NULL leave the per-image sums tot[B][C][2] at red + B*S*C*2 floats (S = adm_gn_splits(HW, C)); the
+ * caller keeps `red` (and ss) alive and queues a row.  table = device array of `rows` rows of 8 int64: {tot, ss (0: none),
+ * ss_bstride, dgamma, dbeta, B, C, block_begin}; a row owns ceil(C / 32) blocks, block_begin = exclusive prefix sum, total_blocks =
+ * the sum.  dgamma[c] += sum_b (1 + scale[b][c]) tot[b][c][1], dbeta[c] += ... tot[b][c][0]: the same order as the per-layer pass. */
+int adm_gn_bwd_param_table(const long* table, int rows, long total_blocks, hipStream_t stream);
+
 /* adm_gn_bwd with dx = (GroupNorm input gradient) + addend[B][HW][C] (addend may be NULL): the block input also feeds the
  * residual branch (uncond_unet.py:189, 201), and adding that branch's gradient here saves autograd's separate
  * read-read-write pass over the activation. */
