@@ -149,10 +149,11 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
 
 
 GEMM_X6_MIN_M = 8192
-# The 1x1 WEIGHT gradient on the split-bf16 kernel (conv_wgrad_x6.hip MODE 1) is correct but not faster than the f32 direct kernel
-# (measured 65-103 vs 47-111 TFLOP/s per shape, step 777 vs 802 images/s: 32x32 wave tiles need two transposed fragment reads per
-# MFMA): kept behind a switch, off.
-GEMM_WGRAD_X6 = os.environ.get("ADM_GEMM_WGRAD_X6", "0") == "1"
+# The 1x1 WEIGHT gradient on the split-bf16 kernel (conv_wgrad_x6.hip MODE 1: four 16-pixel chunks in place of the four ex planes).
+# With the first version of that kernel it was no faster than the f32 direct kernel (65-103 vs 47-111 TFLOP/s per shape); on the
+# twelve-wave version (one plane per consumer wave, 64 x 64 tiles) it is: 84-126 vs 51-109 TFLOP/s on every 1x1 shape of the UNet
+# with >= 8192 pixels, 9.2 -> 7.8 ms per step.  ADM_GEMM_WGRAD_X6=0 -> the f32 kernel.
+GEMM_WGRAD_X6 = os.environ.get("ADM_GEMM_WGRAD_X6", "1") == "1"
 
 
 def _use_gemm_x6(M: int, ks: int, up, n_p: int, k_p: int) -> bool:

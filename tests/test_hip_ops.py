@@ -214,7 +214,7 @@ def test_conv1x1_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, qkv, wit
     (bias, residual, the qkv row permutation), data gradient, and -- through the direct kernels -- weight / bias gradients, against
     F.conv2d on the CPU; ragged pixel counts; then the weights are changed in place and refreshed by repack_all()."""
     monkeypatch.setattr(ops, "BF16X6", True)
-    monkeypatch.setattr(ops, "GEMM_WGRAD_X6", True)          # (off by default: not faster than the f32 direct weight gradient)
+    monkeypatch.setattr(ops, "GEMM_WGRAD_X6", True)          # (the default)
     x = fill.hash_tensor((B, cin, H, H), f"g6x{cin}{cout}", 1.0)
     w = fill.hash_tensor((cout, cin, 1, 1), f"g6w{cin}{cout}", 1.0 / math.sqrt(cin))
     b = fill.hash_tensor((cout,), f"g6b{cin}{cout}", 0.5)
