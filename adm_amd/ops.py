@@ -301,7 +301,7 @@ DEFER_UNPACK = os.environ.get("ADM_DEFER_UNPACK", "1") != "0"
 _rest_ws = {}               # (weight data_ptr, numel) -> zero-at-rest workspace
 _unpack_rows = []           # pending rows of the table (host ints) + the tensors they point into
 _unpack_keep = []
-_unpack_table = None        # (key tuple, device table, total blocks)
+_unpack_tables = {}         # row set -> (device table, total blocks)
 _unpack_queued = False
 _UT_ITEMS = 2048
 
@@ -328,7 +328,8 @@ def _defer_unpack(ws, dst, co, ci, taps, cip, qkv):
 
 _gn_rows = []               # pending GroupNorm parameter-gradient reductions: (tot, ss, bstride, dgamma, dbeta, B, C, blocks)
 _gn_keep = []
-_gn_table = None
+_gn_tables = {}            # row set -> (device table, blocks): with a bucketed reducer every bucket flushes its own set, every step
+_TABLE_CACHE = 256
 
 
 def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
@@ -343,19 +344,21 @@ def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
 
 
 def _flush_gn_params():
-    global _gn_table
     if not _gn_rows:
         return
     # (the partial-sum buffers are fresh allocations, but the caching allocator hands out the same addresses every step: the device
     #  table is re-uploaded -- a synchronising copy -- only when a row changed)
     key = tuple(_gn_rows)
-    if _gn_table is None or _gn_table[0] != key:
+    ent = _gn_tables.get(key)
+    if ent is None:
         rows, begin = [], 0
         for r in _gn_rows:
             rows.append(list(r[:7]) + [begin])
             begin += r[7]
-        _gn_table = (key, torch.tensor(rows, dtype=torch.int64, device=_gn_keep[0][0].device), begin)
-    _, table, blocks = _gn_table
+        if len(_gn_tables) >= _TABLE_CACHE:
+            _gn_tables.clear()
+        ent = _gn_tables[key] = (torch.tensor(rows, dtype=torch.int64, device=_gn_keep[0][0].device), begin)
+    table, blocks = ent
     call("adm_gn_bwd_param_table", ptr(table), len(_gn_rows), blocks)
     _gn_rows.clear()
     _gn_keep.clear()
@@ -364,19 +367,22 @@ def _flush_gn_params():
 def flush_deferred_unpack():
     """Scatter every pending weight-gradient workspace into its gradient (one launch) and clear the workspaces; reduce the pending
     GroupNorm parameter gradients (one launch)."""
-    global _unpack_table, _unpack_queued
+    global _unpack_queued
     _unpack_queued = False
     _flush_gn_params()
     if not _unpack_rows:
         return
     key = tuple(_unpack_rows)
-    if _unpack_table is None or _unpack_table[0] != key:
+    ent = _unpack_tables.get(key)
+    if ent is None:           # (first step only: the upload is a synchronising copy)
         rows, begin = [], 0
         for r in _unpack_rows:
             rows.append(list(r[:9]) + [begin, 0, 0])
             begin += r[9]
-        _unpack_table = (key, torch.tensor(rows, dtype=torch.int64, device=_unpack_keep[0][0].device), begin)
-    _, table, blocks = _unpack_table
+        if len(_unpack_tables) >= _TABLE_CACHE:
+            _unpack_tables.clear()
+        ent = _unpack_tables[key] = (torch.tensor(rows, dtype=torch.int64, device=_unpack_keep[0][0].device), begin)
+    table, blocks = ent
     n = len(_unpack_rows)
     _unpack_rows.clear()
     _unpack_keep.clear()
@@ -410,9 +416,10 @@ def _direct_grad(param):
 
 
 def _notify(param):
+    # (a sink that READS the gradient -- the bucketed reducer when a bucket is complete -- calls flush_deferred_unpack() first:
+    #  weight gradients and GroupNorm parameter gradients may still sit in their workspaces)
     sink = getattr(param, "_adm_grad_sink", None)
     if sink is not None:
-        flush_deferred_unpack()       # the sink reads the gradient now
         sink(param)
 
 

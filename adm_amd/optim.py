@@ -120,6 +120,9 @@ class BucketedGradReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         view = self.flat.grad[lo:hi]
+        # weight / GroupNorm-parameter gradients of the layers seen so far may still sit in their workspaces (ops: deferred
+        # unpack): scatter them now, one launch for everything since the previous bucket
+        ops.flush_deferred_unpack()
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record()
