@@ -99,7 +99,8 @@ __device__ __forceinline__ void lds_barrier() {    // waits for this wave's LDS 
 // MODE 0: the 3x3 Winograd form above.  MODE 1: the weight gradient of a 1x1 conv, dW[co][ci] = sum_pixels dY[p][co] X[p][ci]: the same
 // images, reads and MFMAs with the four `ex` planes of a stage holding four consecutive 16-pixel chunks (64 pixels per stage, no
 // transforms, gridDim.y = 1); the epilogue adds the four accumulators.
-template <int MODE>
+// XBF: x holds bf16 (the bf16-storage activations of the opt-in bf16 mode): 8-byte loads, widened in the producer
+template <int MODE, bool XBF>
 __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smx[];
   unsigned short* As = smx;                        // [2][X_IMG]  dY side: rows = tiles, columns = couts
@@ -146,16 +147,29 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
     const int tl = wid * 4 + (lane >> 4), quad = lane & 15;       // tile of the stage, channel quad
     const unsigned a_col = (co0 + quad * 4 < p.Cout) ? (unsigned)(co0 + quad * 4) * 4u : OOB;
-    const unsigned b_col = (ci0 + quad * 4 < p.Cin) ? (unsigned)(ci0 + quad * 4) * 4u : OOB;
+    constexpr unsigned XB = XBF ? 2u : 4u;          // bytes per x element
+    const unsigned b_col = (ci0 + quad * 4 < p.Cin) ? (unsigned)(ci0 + quad * 4) * XB : OOB;
     const int Wh = p.W >> 1, Hh = p.H >> 1, lwh = p.lw - 1;
     const unsigned ystep = (unsigned)p.lddy * 4u, yrow = (unsigned)p.W * ystep;
-    const unsigned xstep = (unsigned)p.ldx * 4u;
+    const unsigned xstep = (unsigned)p.ldx * XB;
     const int iA = (ey == 0) ? 0 : 1, iB = (ey == 3) ? 3 : 2;       // X rows of this pass: (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey]
     // y combination of this pass as a + sgn b: dY rows (r0, r0 + r1, r0 - r1, -r1)[ey], X rows (r0 - r2, r1 + r2, -(r2 - r1), r1 - r3)[ey]
     const float sg = x_side ? (ey == 1 ? 1.f : -1.f) : (ey <= 1 ? 1.f : -1.f);
     const f32x2 sgn = {sg, sg};
     constexpr int D = 3;                           // stages in flight
     f32x4 u0[D][4], u1[D][4];                      // dY side: u0 = (r0 px0, r0 px1, r1 px0, r1 px1); X side: u0 / u1 = rows iA / iB
+    // four channels of x at a byte offset: f32 = one 16-byte load; bf16 = one 8-byte load kept RAW in two lanes (widening at the load
+    // would put a wait right behind it) and widened by wide4() when the set is consumed
+    auto ldx4 = [&](unsigned off) -> f32x4 {
+      if (!XBF) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+      const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, (int)off, 0, 0));
+      return f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), 0.f, 0.f};
+    };
+    auto wide4 = [&](f32x4 v) -> f32x4 {
+      if (!XBF) return v;
+      const unsigned r0 = __float_as_uint(v[0]), r1 = __float_as_uint(v[1]);
+      return f32x4{__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xFFFF0000u), __uint_as_float(r1 << 16), __uint_as_float(r1 & 0xFFFF0000u)};
+    };
     auto issue = [&](int d, int s) {               // loads of stage s -> register set d (stages past the end read nothing)
       if (MODE == 1) {                             // chunk xi of the stage: pixel pbeg + 64 s + 16 xi + tl, one quad of dY or of X
 #pragma unroll
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
           const int px = pbeg + s * STEP + xi * XK + tl;
           const bool pv = px < pend && s < KT;
           if (!x_side) u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)((pv && a_col != OOB) ? (unsigned)px * ystep + a_col : OOB), 0, 0));
-          else u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((pv && b_col != OOB) ? (unsigned)px * xstep + b_col : OOB), 0, 0));
+          else u0[d][xi] = ldx4((pv && b_col != OOB) ? (unsigned)px * xstep + b_col : OOB);
         }
         return;
       }
@@ -197,8 +211,8 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
       for (int j = 0; j < 4; ++j) {
         const bool cv = (j != 0 || xp > 0) && (j != 3 || xp < Wh - 1);
         const unsigned cj = p.up ? (unsigned)(((j + 1) >> 1) - 1) * xstep : (unsigned)j * xstep;
-        u0[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vA && cv) ? xa + cj : OOB), 0, 0));
-        u1[d][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((vB && cv) ? xb + cj : OOB), 0, 0));
+        u0[d][j] = ldx4((vA && cv) ? xa + cj : OOB);
+        u1[d][j] = ldx4((vB && cv) ? xb + cj : OOB);
       }
     };
     // the bias gradient = sum of every dY pixel = the ex = 1 component (e0 + e1 along x) of the ey = 1 workgroups (r0 + r1 along y)
@@ -211,6 +225,11 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
       if (XW_ABL & 2) return;
       if (MODE == 1) {
         if (do_bias) bsum += (u0[d][0] + u0[d][1]) + (u0[d][2] + u0[d][3]);
+        if (x_side && XBF) {
+          const f32x4 w[4] = {wide4(u0[d][0]), wide4(u0[d][1]), wide4(u0[d][2]), wide4(u0[d][3])};
+          store_planes(w, lb + slot * X_IMG);
+          return;
+        }
         store_planes(u0[d], (x_side ? lb : la) + slot * X_IMG);
         return;
       }
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
       }
       f32x4 dd[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dd[j] = fma4s(u0[d][j], u1[d][j], sgn);     // rows iA +- iB; the pass ey = 2 wants iB - iA: the epilogue negates
+      for (int j = 0; j < 4; ++j) dd[j] = fma4s(wide4(u0[d][j]), wide4(u1[d][j]), sgn);     // rows iA +- iB; the pass ey = 2 wants iB - iA: the epilogue negates
       const f32x4 b[4] = {sub4x(dd[0], dd[2]), dd[1] + dd[2], sub4x(dd[2], dd[1]), sub4x(dd[1], dd[3])};
       store_planes(b, lb + slot * X_IMG);
     };
@@ -368,15 +387,14 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
 }
 
 int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int mode = 0);
+                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int xbf = 0);
 
 // MODE 1 host side: P pixels, no geometry
 int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
-                      bool det, bool plan_only, hipStream_t stream);
+                      bool det, bool plan_only, hipStream_t stream, int xbf = 0);
 
 int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int mode) {
-  (void)mode;
+                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int xbf) {
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
   if (B <= 0 || H < 2 || W < 2) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
@@ -387,7 +405,7 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   WxP p;
   p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
   const long P = (long)B * H * W;
-  const long xb = (up ? P / 4 : P) * ldx * 4, db = P * lddy * 4;
+  const long xb = (up ? P / 4 : P) * ldx * (xbf ? 2 : 4), db = P * lddy * 4;
   if (xb >= (1L << 31) - (1L << 22) || db >= (1L << 31) - (1L << 22)) return ADM_EINVAL;   // 32-bit offsets
   p.up = up ? 1 : 0;
   p.Pp = (int)(P / 4); p.H = H; p.W = W; p.lw = lw; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
@@ -420,24 +438,27 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+            hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   p.tiles = adm_cdiv(Cout, XT) * p.tilesN;
   dim3 grid(p.tiles * 4 * splits);
-  hipLaunchKernelGGL(wgrad_x6_kernel<0>, grid, dim3(768), smem, stream, p);
+  if (xbf) hipLaunchKernelGGL((wgrad_x6_kernel<0, true>), grid, dim3(768), smem, stream, p);
+  else hipLaunchKernelGGL((wgrad_x6_kernel<0, false>), grid, dim3(768), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
 
 int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
-                      bool det, bool plan_only, hipStream_t stream) {
+                      bool det, bool plan_only, hipStream_t stream, int xbf) {
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
   if (P <= 0 || (Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
   if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
-  const long xb = P * ldx * 4, db = P * lddy * 4;
+  const long xb = P * ldx * (xbf ? 2 : 4), db = P * lddy * 4;
   if (P >= (1L << 30) || xb >= (1L << 31) || db >= (1L << 31)) return ADM_EINVAL;
   WxP p;
   p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
@@ -470,14 +491,17 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
   constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+            hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   p.tiles = adm_cdiv(Cout, XT) * p.tilesN;
   dim3 grid(p.tiles * splits);
-  hipLaunchKernelGGL(wgrad_x6_kernel<1>, grid, dim3(768), smem, stream, p);
+  if (xbf) hipLaunchKernelGGL((wgrad_x6_kernel<1, true>), grid, dim3(768), smem, stream, p);
+  else hipLaunchKernelGGL((wgrad_x6_kernel<1, false>), grid, dim3(768), smem, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -518,4 +542,17 @@ extern "C" int adm_gemm_wgrad_x6_ws(const float* x, const float* dy, float* ws, 
 }
 extern "C" int adm_gemm_wgrad_x6_plan(long P, int Cin, int Cout) {
   return wgrad_x6_1x1_impl(nullptr, nullptr, nullptr, nullptr, P, Cin, Cin, Cout, Cout, 0, false, true, nullptr);
+}
+
+// The same kernels with x stored as bf16 (the opt-in bf16 mode keeps its GroupNorm outputs in bf16: adm_gn_fwd_bf16out): the products
+// are then exact in x and three-term exact in dy.  x16 = [B][H][W][ldx] bf16 ([B][H/2][W/2][ldx] with up); everything else as in
+// adm_conv_wgrad_x6 / adm_gemm_wgrad_x6.
+extern "C" int adm_conv_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx,
+                                       int Cout, int lddy, int splits, int up, hipStream_t stream) {
+  return wgrad_x6_impl(static_cast<const float*>(x16), dy, dwp2, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, false, false, up ? 1 : 0,
+                       stream, 1);
+}
+extern "C" int adm_gemm_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout,
+                                       int lddy, int splits, hipStream_t stream) {
+  return wgrad_x6_1x1_impl(static_cast<const float*>(x16), dy, dwp, dbias, P, Cin, ldx, Cout, lddy, splits, false, false, stream, 1);
 }

@@ -580,14 +580,18 @@ class _Conv(torch.autograd.Function):
                     else:
                         dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
-                wino_w = (not bf16 and _use_wino(B, Ho, Wo, ks, up, -1) and not qkv and pow2(Ho) and pow2(Wo))
-                wino2_w = wino_w and WINOGRAD2D and (not up or BF16X6) and Ho >= 2   # 2-D F(3x3, 2x2): 12 x-folded planes per cout
+                wino_ok = _use_wino(B, Ho, Wo, ks, up, -1) and not qkv and pow2(Ho) and pow2(Wo)
+                # bf16 mode: the split-bf16 Winograd kernel (dy split exactly, x bf16 or f32) is faster than the direct bf16 weight
+                # gradient (~250 vs 179 TFLOP/s algorithmic) and more accurate
+                x6_bf = bf16 and BF16X6 and WINOGRAD2D and wino_ok and Ho >= 2
+                wino_w = not bf16 and wino_ok
+                wino2_w = (wino_w and WINOGRAD2D and (not up or BF16X6) and Ho >= 2) or x6_bf   # 2-D F(3x3, 2x2): 12 x-folded planes per cout
                 wmode = 2 if wino2_w else int(wino_w)
                 planes = 12 if wino2_w else ks * ks
                 det = DETERMINISTIC and not bf16
                 defer = DEFER_UNPACK and wsink is not None and not det and side is None
                 x6_w = wino2_w and BF16X6          # f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip)
-                g6_w = GEMM_WGRAD_X6 and BF16X6 and not bf16 and ks == 1 and not up and B * Ho * Wo >= GEMM_X6_MIN_M      # ... 1x1 convs (its MODE 1)
+                g6_w = GEMM_WGRAD_X6 and BF16X6 and ks == 1 and not up and B * Ho * Wo >= GEMM_X6_MIN_M      # ... 1x1 convs (its MODE 1)
                 splits = 1
                 if det:        # splits store partial tiles to a workspace; the unpack launch sums them in a fixed order
                     splits = (hip.lib().adm_conv_wgrad_x6_plan(B, Ho, Wo, cip, cop) if x6_w else
@@ -605,7 +609,11 @@ class _Conv(torch.autograd.Function):
                 kind = "wgrad_wino2x6" if x6_w else "wgrad_gemmx6" if g6_w else "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
                 with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"{kind.replace('_', '-')} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
-                    if bf16:
+                    if bf16 and x6_w and x.dtype == torch.bfloat16:
+                        call("adm_conv_wgrad_x6_bf16a", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B, Ho, Wo, cip, cip, cop, cop, auto, int(up))
+                    elif bf16 and g6_w and x.dtype == torch.bfloat16:
+                        call("adm_gemm_wgrad_x6_bf16a", ptr(x), ptr(dy), ptr(dwp), ptr(dbp), B * Ho * Wo, cip, cip, cop, cop, auto)
+                    elif bf16 and not (x6_w or g6_w):
                         call("adm_conv_wgrad_bf16a" if x.dtype == torch.bfloat16 else "adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho,
                              Wo, cip, cip, cop, cop, ks, int(up), auto)
                     elif det and g6_w:

@@ -139,6 +139,12 @@ int adm_gemm_wgrad_x6(const float* x, const float* dy, float* dwp, float* dbias,
 int adm_gemm_wgrad_x6_ws(const float* x, const float* dy, float* ws, float* bws, long P, int Cin, int ldx, int Cout, int lddy,
                          int splits, hipStream_t stream);
 int adm_gemm_wgrad_x6_plan(long P, int Cin, int Cout);
+/* The same two weight gradients with x stored as bf16 (the opt-in bf16 mode's GroupNorm outputs, adm_gn_fwd_bf16out): x16 =
+ * [B][H][W][ldx] bf16 ([B][H/2][W/2][ldx] when up); products exact in x, three-term exact in dy, f32 accumulate. */
+int adm_conv_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx,
+                            int Cout, int lddy, int splits, int up, hipStream_t stream);
+int adm_gemm_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy,
+                            int splits, hipStream_t stream);
 /* kernel variant of adm_conv_fwd_wino2d: -1 (default) chosen per launch, 1 wave-specialised (producer / consumer waves), 0 symmetric;
  * returns the old value */
 int adm_wino2d_variant(int ws);

@@ -61,10 +61,15 @@ def test_conv_bf16_forward_backward(ops_bf16, cin, cout, H, ks, up):
     if cop % 64 == 0:       # dgrad ran in bf16 (else the fp32 kernel handled it)
         torch.testing.assert_close(xd.grad.cpu().permute(0, 3, 1, 2)[:, :cin], xr.grad, rtol=2e-4,
                                    atol=2e-4 * float(xr.grad.abs().max()))
-    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=2e-4, atol=3e-4 * float(wr.grad.abs().max()))
-    # (2) versus full fp32: bf16-level error only
     y32, x32, w32 = ref(x, w, gy)
     y32.backward(gy)
+    pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
+    if ops.BF16X6 and ops.WINOGRAD2D and ks == 3 and pow2(Ho) and ops._use_wino(B, Ho, Ho, ks, up, -1):
+        # the 3x3 weight gradient runs on the split-bf16 Winograd kernel (dy split exactly, x not rounded here): f32 accuracy
+        torch.testing.assert_close(wd.grad.cpu(), w32.grad, rtol=2e-4, atol=2e-5 * float(w32.grad.abs().max()))
+    else:
+        torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=2e-4, atol=3e-4 * float(wr.grad.abs().max()))
+    # (2) versus full fp32: bf16-level error only
     assert float((yh - y32.detach()).abs().max()) <= 2e-2 * float(y32.abs().max())
     assert float((wd.grad.cpu() - w32.grad).abs().max()) <= 2e-2 * float(w32.grad.abs().max())
     torch.testing.assert_close(bd.grad.cpu(), gy.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4 * float(gy.sum(dim=(0, 2, 3)).abs().max()))
@@ -166,3 +171,39 @@ def test_unet_bf16_storage_equals_rounding_on_load(ops_bf16, monkeypatch):
     assert len(on[2]) == len(off[2]) > 50
     for u, v in zip(on[2], off[2]):
         assert float((u - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-3)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,up,ks", [(8, 64, 96, 32, False, 3), (4, 96, 64, 16, True, 3), (16, 192, 192, 16, False, 3),
+                                                (8, 64, 128, 32, False, 1), (3, 96, 96, 8, False, 1)])
+def test_wgrad_x6_bf16_activations_equal_f32_kernel_on_rounded_x(ops_bf16, B, cin, cout, H, up, ks):
+    """adm_conv_wgrad_x6_bf16a / adm_gemm_wgrad_x6_bf16a (x stored as bf16) against the f32-input kernels fed the same values
+    widened to f32: identical products, split-K atomics reorder the sums (1e-6 of the scale)."""
+    from adm_amd import hip
+    gpu = torch.device("cuda:0")
+    Hin = H // 2 if up else H
+    x = fill.hash_tensor((B, Hin, Hin, cin), f"xb{cin}{cout}{H}", 1.0)
+    dy = fill.hash_tensor((B, H, H, cout), f"gb{cin}{cout}{H}", 0.05)
+    x16 = x.to(torch.bfloat16).to(gpu)
+    xf = x16.to(torch.float32)
+    dyd = dy.to(gpu)
+    planes = 12 if ks == 3 else 1
+    out = []
+    for which in (0, 1):
+        dwp = torch.zeros((cout, planes * cin), device=gpu)
+        db = torch.zeros((cout,), device=gpu)
+        if ks == 3:
+            if which:
+                hip.call("adm_conv_wgrad_x6_bf16a", hip.ptr(x16), hip.ptr(dyd), hip.ptr(dwp), hip.ptr(db), B, H, H, cin, cin, cout, cout, 0,
+                         int(up))
+            else:
+                hip.call("adm_conv_wgrad_x6_up" if up else "adm_conv_wgrad_x6", hip.ptr(xf), hip.ptr(dyd), hip.ptr(dwp), hip.ptr(db), B, H, H,
+                         cin, cin, cout, cout, 0)
+        else:
+            hip.call("adm_gemm_wgrad_x6_bf16a" if which else "adm_gemm_wgrad_x6", hip.ptr(x16 if which else xf), hip.ptr(dyd), hip.ptr(dwp),
+                     hip.ptr(db), B * H * H, cin, cin, cout, cout, 0)
+        torch.cuda.synchronize()
+        out.append((dwp.cpu(), db.cpu()))
+    scale = float(out[0][0].abs().max())
+    assert scale > 0
+    assert float((out[0][0] - out[1][0]).abs().max()) <= 2e-6 * scale
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-6 * float(out[0][1].abs().max())
