@@ -369,6 +369,8 @@ def flush_deferred_unpack():
     GroupNorm parameter gradients (one launch)."""
     global _unpack_queued
     _unpack_queued = False
+    if _side_stream is not None:      # weight gradients produced on the side stream (SIDE_WGRAD) must have landed
+        torch.cuda.current_stream().wait_stream(_side_stream)
     _flush_gn_params()
     if not _unpack_rows:
         return
@@ -423,12 +425,13 @@ def _notify(param):
         sink(param)
 
 
-# Weight/bias gradients are side results of the backward chain: when they can be accumulated directly (flat
-# gradient buffer) they CAN be computed on a side stream, concurrently with the data-gradient chain on the main
-# stream (the HBM-bound GroupNorm backward under the MFMA-bound weight-gradient GEMMs).  Measured on MI355X at
-# bs=128: 266.2 vs 265.2 ms/step (fp32), 140.2 vs 141.2 (bf16 mode) -- no gain, the resident workgroups of
-# whichever GEMM runs first hold the CUs -- so it is OFF by default and kept only as a switch.
-SIDE_WGRAD = False
+# Weight/bias gradients are side results of the backward chain: when they can be accumulated directly (flat gradient buffer) they
+# are computed on a side stream, concurrently with the data-gradient chain on the main stream.  The split-bf16 kernels occupy a
+# whole CU per workgroup, so the two streams never share a CU -- what overlaps is one kernel's tail (its last, partly filled round
+# of workgroups and its slowest workgroups) with the next kernel's head.  Round 1 (f32-MFMA kernels at two workgroups per CU):
+# 266.2 vs 265.2 ms/step, no gain, off.  Now (one workgroup per CU, ~350 us kernels): 149.6 vs 152.6 ms/step in the same run
+# (855.6 vs 838.6 images/s) -- on by default with direct gradients; ADM_SIDE_WGRAD=0 keeps everything on one stream.
+SIDE_WGRAD = os.environ.get("ADM_SIDE_WGRAD", "1") == "1"
 _side_stream = None
 
 
@@ -589,7 +592,7 @@ class _Conv(torch.autograd.Function):
                 wmode = 2 if wino2_w else int(wino_w)
                 planes = 12 if wino2_w else ks * ks
                 det = DETERMINISTIC and not bf16
-                defer = DEFER_UNPACK and wsink is not None and not det and side is None
+                defer = DEFER_UNPACK and wsink is not None and not det      # (with a side stream: the flush joins it first)
                 x6_w = wino2_w and BF16X6          # f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip)
                 g6_w = GEMM_WGRAD_X6 and BF16X6 and ks == 1 and not up and B * Ho * Wo >= GEMM_X6_MIN_M      # ... 1x1 convs (its MODE 1)
                 splits = 1

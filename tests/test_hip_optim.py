@@ -220,3 +220,32 @@ def test_deferred_unpack_matches_per_layer_launches():
         ops.DEFER_UNPACK = old
     scale = float(grads[0].abs().max())
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
+
+
+def test_side_stream_weight_gradients_match_single_stream():
+    """ops.SIDE_WGRAD (weight / bias gradients on a side stream, joined before the end-of-backward unpack) against the
+    single-stream order: same gradients over repeated steps (split-K atomics reorder sums: 1e-5 relative), workspaces zero."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import ops
+    from adm_amd.optim import FlatParams
+    gpu = torch.device("cuda:0")
+    grads = []
+    old = ops.SIDE_WGRAD
+    try:
+        for side in (False, True):
+            ops.SIDE_WGRAD = side
+            m = _model(gpu)
+            flat = FlatParams(m)
+            for _ in range(3):
+                flat.zero_grad()
+                _loss(m, gpu).backward()
+            torch.cuda.synchronize()
+            grads.append(flat.grad.clone())
+            for ws in ops._rest_ws.values():
+                assert float(ws.abs().max()) == 0.0
+    finally:
+        ops.SIDE_WGRAD = old
+    scale = float(grads[0].abs().max())
+    assert scale > 0 and bool(torch.isfinite(grads[1]).all())
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
