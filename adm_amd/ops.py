@@ -371,6 +371,8 @@ def flush_deferred_unpack():
     _unpack_queued = False
     if _side_stream is not None:      # weight gradients produced on the side stream (SIDE_WGRAD) must have landed
         torch.cuda.current_stream().wait_stream(_side_stream)
+    if _branch_stream is not None:    # ... and the second decoder's backward (its GroupNorm partial sums, its bias gradients)
+        torch.cuda.current_stream().wait_stream(_branch_stream)
     _flush_gn_params()
     if not _unpack_rows:
         return
@@ -444,12 +446,32 @@ def _wgrad_stream():
 
 _join_queued = False
 
+# The two decoders of the two-output UNet are independent between the encoder and the preconditioning: the second one runs on its
+# own stream (forward; autograd then runs its backward nodes there too), so that the kernels of the two chains fill each other's
+# tails.  ADM_BRANCH_STREAM=0 keeps one stream.
+BRANCH_STREAM = os.environ.get("ADM_BRANCH_STREAM", "1") == "1"
+_branch_stream = None
+
+
+def branch_stream():
+    """The stream of the second decoder, made to wait for everything enqueued so far on the current stream; None when the branch
+    must stay on the current stream (stream capture, switched off)."""
+    global _branch_stream
+    if not BRANCH_STREAM or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return None
+    if _branch_stream is None:
+        _branch_stream = torch.cuda.Stream()
+    _branch_stream.wait_stream(torch.cuda.current_stream())
+    return _branch_stream
+
 
 def join_side_streams():
     global _join_queued
     _join_queued = False
     if _side_stream is not None:
         torch.cuda.current_stream().wait_stream(_side_stream)
+    if _branch_stream is not None:
+        torch.cuda.current_stream().wait_stream(_branch_stream)
 
 
 def _queue_join_at_end_of_backward():

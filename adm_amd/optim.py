@@ -132,6 +132,8 @@ class BucketedGradReducer:
                 # bucket were written on the main stream, or the other way round: order the all-reduce after BOTH
                 if ops._side_stream is not None:
                     self.side.wait_stream(ops._side_stream)
+                if ops._branch_stream is not None:
+                    self.side.wait_stream(ops._branch_stream)
                 self.side.wait_stream(self.main)
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

@@ -274,8 +274,16 @@ class DhariwalUNet(nn.Module):
         if self.variant == "uncond_unet_sd_3":          # skip-tuning (uncond_unet_sd_3.py:547-555)
             n = len(skips)
             ratios = [0.5 + 0.5 * i / (n - 1) for i in range(n)][::-1]
-        f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios)
         f_y = None
+        s2 = ops.branch_stream() if (self.two_decoders and x.is_cuda) else None
+        if s2 is not None:      # the second decoder on its own stream, concurrently with the first (ops.BRANCH_STREAM)
+            main = torch.cuda.current_stream()
+            with torch.cuda.stream(s2):
+                f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2)
+            f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios)
+            main.wait_stream(s2)
+            return f_x, f_y
+        f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios)
         if self.two_decoders:
             f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2)
         return f_x, f_y

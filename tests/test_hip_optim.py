@@ -249,3 +249,39 @@ def test_side_stream_weight_gradients_match_single_stream():
     scale = float(grads[0].abs().max())
     assert scale > 0 and bool(torch.isfinite(grads[1]).all())
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
+
+
+def test_second_decoder_on_its_own_stream_matches_single_stream():
+    """ops.BRANCH_STREAM (the second decoder of the two-output UNet on its own stream, forward and backward) against one stream:
+    bit-identical outputs, gradients equal up to the split-K atomics' summation order, over repeated steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import ops
+    from adm_amd.optim import FlatParams
+    gpu = torch.device("cuda:0")
+    x = fill.hash_tensor((2, 3, 32, 32), "x", 1.0).to(gpu)
+    sigma = torch.tensor([0.05, 0.7], device=gpu)
+    outs, grads = [], []
+    old = ops.BRANCH_STREAM
+    try:
+        for branch in (False, True):
+            ops.BRANCH_STREAM = branch
+            m = _model(gpu)
+            with torch.no_grad():
+                for _ in range(2):
+                    dx, dy = m(x, sigma)
+            torch.cuda.synchronize()
+            outs.append((dx.clone(), dy.clone()))
+            flat = FlatParams(m)
+            for _ in range(3):
+                flat.zero_grad()
+                _loss(m, gpu).backward()
+            torch.cuda.synchronize()
+            grads.append(flat.grad.clone())
+    finally:
+        ops.BRANCH_STREAM = old
+    assert ops._branch_stream is not None
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    scale = float(grads[0].abs().max())
+    assert scale > 0 and bool(torch.isfinite(grads[1]).all())
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
