@@ -263,9 +263,13 @@ def main():
     sample_ips = None
     # one more step with per-launch HIP events.  EVERY rank runs it (the step contains the gradient all-reduces: a step
     # on rank 0 alone would wait for its peers forever); only rank 0 records and reports.
+    # The profiled step runs on ONE stream (the weight gradients' side stream is off under PROFILE; the second decoder's
+    # stream is switched off here): a kernel that shares the CUs with a kernel of another stream reads longer than it is.
     if rank == 0:
         ops.PROFILE = []
+    branch, ops.BRANCH_STREAM = ops.BRANCH_STREAM, False
     train_step(args.warmup + args.steps)
+    ops.BRANCH_STREAM = branch
     barrier()
     if reducer.active:        # two more untimed steps that measure how much of the all-reduce is NOT hidden under backward
         reducer.measure = True

@@ -7,6 +7,9 @@ R=$PWD
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# one stream: a kernel that shares the CUs with a kernel of another stream reads longer than it is (the untraced step overlaps
+# the weight gradients and the second decoder with the main chain: ADM_SIDE_WGRAD / ADM_BRANCH_STREAM, on by default)
+export ADM_SIDE_WGRAD=0 ADM_BRANCH_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/long -- python3 $R/bench.py --steps 5 --warmup 1 --profile-only > $O/long.log 2>&1
 echo "long trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/short -- python3 $R/bench.py --steps 1 --warmup 1 --profile-only > $O/short.log 2>&1

@@ -56,7 +56,8 @@ if short_dir:
            f"other one-time launches are out of the per-step figures below ({nsteps} steps remain).", ""]
 md += [f"Kernel time per steady-state step: **{tot_ss / 1e6 / nsteps:.1f} ms**, {sum(v[1] for v in by.values()) / nsteps:.0f} launches "
        f"(whole trace: {tot / 1e6:.1f} ms).  The sum exceeds the wall-clock step of an untraced run because the tracer adds a "
-       "fixed cost to every dispatch and removes the overlap of the side-stream weight gradients with the main stream.", "",
+       "fixed cost to every dispatch, and because the traced run keeps everything on ONE stream (ADM_SIDE_WGRAD=0 ADM_BRANCH_STREAM=0: "
+       "true per-kernel durations) while the untraced step overlaps the weight gradients and the second decoder with the main chain.", "",
        "| class | launches/step | ms/step | avg launch us |", "|---|---|---|---|"]
 for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0]):
     if n > 0:
