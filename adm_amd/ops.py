@@ -304,6 +304,13 @@ _unpack_keep = []
 _unpack_tables = {}         # row set -> (device table, total blocks)
 _unpack_queued = False
 _UT_ITEMS = 2048
+_producer_streams = {}      # streams on which queued work was produced since the last flush (the flush waits for them)
+
+
+def _note_producer_stream():
+    if torch.cuda.is_available():
+        st = torch.cuda.current_stream()
+        _producer_streams[st.cuda_stream] = st
 
 
 def _rest_workspace(weight, shape, like):
@@ -321,6 +328,7 @@ def _defer_unpack(ws, dst, co, ci, taps, cip, qkv):
     items = co * ci * (taps if taps else 3)
     _unpack_rows.append((ws.data_ptr(), dst.data_ptr(), co, ci, taps, cip, int(qkv), 1, 1, (items + _UT_ITEMS - 1) // _UT_ITEMS))
     _unpack_keep.append((ws, dst))
+    _note_producer_stream()
     if not _unpack_queued:
         _unpack_queued = True
         torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
@@ -338,6 +346,7 @@ def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
     _gn_rows.append((red.data_ptr() + 4 * tot_off, 0 if ss is None else ss.data_ptr(), int(bstride), dgamma.data_ptr(),
                      dbeta.data_ptr(), B, C, (C + 31) // 32))
     _gn_keep.append((red, ss, dgamma, dbeta))
+    _note_producer_stream()
     if not _unpack_queued:
         _unpack_queued = True
         torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
@@ -369,10 +378,14 @@ def flush_deferred_unpack():
     GroupNorm parameter gradients (one launch)."""
     global _unpack_queued
     _unpack_queued = False
-    if _side_stream is not None:      # weight gradients produced on the side stream (SIDE_WGRAD) must have landed
-        torch.cuda.current_stream().wait_stream(_side_stream)
-    if _branch_stream is not None:    # ... and the second decoder's backward (its GroupNorm partial sums, its bias gradients)
-        torch.cuda.current_stream().wait_stream(_branch_stream)
+    # whatever was queued must have landed: the weight gradients produced on the side stream (SIDE_WGRAD), the second decoder's
+    # GroupNorm partial sums (BRANCH_STREAM), the main chain's when a reducer bucket flushes from inside a side-stream section
+    if torch.cuda.is_available() and _producer_streams:
+        cur = torch.cuda.current_stream()
+        for key, st in list(_producer_streams.items()):
+            if key != cur.cuda_stream:
+                cur.wait_stream(st)
+        _producer_streams.clear()
     _flush_gn_params()
     if not _unpack_rows:
         return
