@@ -307,6 +307,22 @@ _UT_ITEMS = 2048
 _producer_streams = {}      # streams on which queued work was produced since the last flush (the flush waits for them)
 
 
+_pinned_tables = []         # host copies of uploaded tables (pinned: the copy is asynchronous; kept alive with the cache)
+
+
+def _upload_table(rows, device):
+    """int64 table -> device without stalling the host: a pageable source would make the copy wait for everything enqueued so far
+    (the whole backward pass), once per new row set -- and the GroupNorm row sets (fresh allocations) take a few steps to repeat."""
+    host = torch.tensor(rows, dtype=torch.int64)
+    if device.type != "cuda":
+        return host.to(device)
+    host = host.pin_memory()
+    if len(_pinned_tables) >= 4 * _TABLE_CACHE:
+        del _pinned_tables[: 2 * _TABLE_CACHE]
+    _pinned_tables.append(host)
+    return host.to(device, non_blocking=True)
+
+
 def _note_producer_stream():
     if torch.cuda.is_available():
         st = torch.cuda.current_stream()
@@ -338,6 +354,7 @@ _gn_rows = []               # pending GroupNorm parameter-gradient reductions: (
 _gn_keep = []
 _gn_tables = {}            # row set -> (device table, blocks): with a bucketed reducer every bucket flushes its own set, every step
 _TABLE_CACHE = 256
+table_uploads = 0           # diagnostics: host->device table copies (asynchronous, from pinned memory)
 
 
 def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
@@ -366,7 +383,9 @@ def _flush_gn_params():
             begin += r[7]
         if len(_gn_tables) >= _TABLE_CACHE:
             _gn_tables.clear()
-        ent = _gn_tables[key] = (torch.tensor(rows, dtype=torch.int64, device=_gn_keep[0][0].device), begin)
+        ent = _gn_tables[key] = (_upload_table(rows, _gn_keep[0][0].device), begin)
+        global table_uploads
+        table_uploads += 1
     table, blocks = ent
     call("adm_gn_bwd_param_table", ptr(table), len(_gn_rows), blocks)
     _gn_rows.clear()
@@ -398,7 +417,9 @@ def flush_deferred_unpack():
             begin += r[9]
         if len(_unpack_tables) >= _TABLE_CACHE:
             _unpack_tables.clear()
-        ent = _unpack_tables[key] = (torch.tensor(rows, dtype=torch.int64, device=_unpack_keep[0][0].device), begin)
+        ent = _unpack_tables[key] = (_upload_table(rows, _unpack_keep[0][0].device), begin)
+        global table_uploads
+        table_uploads += 1
     table, blocks = ent
     n = len(_unpack_rows)
     _unpack_rows.clear()

@@ -239,6 +239,7 @@ def main():
     for i in range(args.warmup):
         train_step(i)
     barrier()
+    uploads0 = ops.table_uploads
     log("warm-up done; timing")
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -254,6 +255,7 @@ def main():
             dist.destroy_process_group()
         return
     ms_per_step = dt / args.steps * 1e3
+    log(f"gradient-table uploads (pinned, asynchronous): {uploads0} in the warm-up, {ops.table_uploads - uploads0} in the timed steps")
     log(f"{args.steps} steps in {dt:.3f}s = {ms_per_step:.1f} ms/step")
     value = world * B * args.steps / dt
     final_loss = float(loss.detach())
