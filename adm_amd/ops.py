@@ -302,8 +302,36 @@ _rest_ws = {}               # (weight data_ptr, numel) -> zero-at-rest workspace
 _unpack_rows = []           # pending rows of the table (host ints) + the tensors they point into
 _unpack_keep = []
 _unpack_tables = {}         # row set -> (device table, total blocks)
-_unpack_queued = False
+_unpack_queued = -2         # id of the backward pass (autograd graph task) whose end-of-pass callback is queued
 _UT_ITEMS = 2048
+
+
+def _graph_task_id() -> int:
+    """Id of the running backward pass (-1 outside one).  The end-of-pass callbacks are queued once per pass; keying the "queued"
+    mark by the pass id (not a flag) means a pass that raised half-way cannot leave the mark set for every later pass."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
+_rows_task = -2             # the pass the pending rows belong to
+
+
+def _begin_defer():
+    """Rows left over from a pass that never reached its end (it raised): drop them and re-zero the workspaces they point to."""
+    global _rows_task
+    tid = _graph_task_id()
+    if tid >= 0 and _rows_task != tid:
+        if _unpack_rows or _gn_rows:
+            reset_deferred_unpack()
+        _rows_task = tid
+
+
+def _queue_flush():
+    global _unpack_queued
+    tid = _graph_task_id()
+    if tid < 0 or _unpack_queued != tid:       # (no id available: queue every time -- the flush is idempotent)
+        _unpack_queued = tid
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
 _producer_streams = {}      # streams on which queued work was produced since the last flush (the flush waits for them)
 
 
@@ -340,14 +368,12 @@ def _rest_workspace(weight, shape, like):
 
 def _defer_unpack(ws, dst, co, ci, taps, cip, qkv):
     """Queue `dst (OIHW) += unpack(ws)` for the end-of-backward table launch; taps = 0 for the 2-D Winograd planes."""
-    global _unpack_queued
+    _begin_defer()
     items = co * ci * (taps if taps else 3)
     _unpack_rows.append((ws.data_ptr(), dst.data_ptr(), co, ci, taps, cip, int(qkv), 1, 1, (items + _UT_ITEMS - 1) // _UT_ITEMS))
     _unpack_keep.append((ws, dst))
     _note_producer_stream()
-    if not _unpack_queued:
-        _unpack_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
+    _queue_flush()
 
 
 _gn_rows = []               # pending GroupNorm parameter-gradient reductions: (tot, ss, bstride, dgamma, dbeta, B, C, blocks)
@@ -359,14 +385,12 @@ table_uploads = 0           # diagnostics: host->device table copies (asynchrono
 
 def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
     """Queue `dgamma, dbeta += batch reduction of the per-image sums` for the end-of-backward table launch."""
-    global _unpack_queued
+    _begin_defer()
     _gn_rows.append((red.data_ptr() + 4 * tot_off, 0 if ss is None else ss.data_ptr(), int(bstride), dgamma.data_ptr(),
                      dbeta.data_ptr(), B, C, (C + 31) // 32))
     _gn_keep.append((red, ss, dgamma, dbeta))
     _note_producer_stream()
-    if not _unpack_queued:
-        _unpack_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_unpack)
+    _queue_flush()
 
 
 def _flush_gn_params():
@@ -396,7 +420,7 @@ def flush_deferred_unpack():
     """Scatter every pending weight-gradient workspace into its gradient (one launch) and clear the workspaces; reduce the pending
     GroupNorm parameter gradients (one launch)."""
     global _unpack_queued
-    _unpack_queued = False
+    _unpack_queued = -2
     # whatever was queued must have landed: the weight gradients produced on the side stream (SIDE_WGRAD), the second decoder's
     # GroupNorm partial sums (BRANCH_STREAM), the main chain's when a reducer bucket flushes from inside a side-stream section
     if torch.cuda.is_available() and _producer_streams:
@@ -430,7 +454,7 @@ def flush_deferred_unpack():
 def reset_deferred_unpack():
     """Drop pending rows and re-zero every workspace (after a backward pass that raised half-way)."""
     global _unpack_queued
-    _unpack_queued = False
+    _unpack_queued = -2
     _unpack_rows.clear()
     _unpack_keep.clear()
     _gn_rows.clear()
@@ -478,7 +502,7 @@ def _wgrad_stream():
     return _side_stream
 
 
-_join_queued = False
+_join_queued = -2
 
 # The two decoders of the two-output UNet are independent between the encoder and the preconditioning: the second one runs on its
 # own stream (forward; autograd then runs its backward nodes there too), so that the kernels of the two chains fill each other's
@@ -501,7 +525,7 @@ def branch_stream():
 
 def join_side_streams():
     global _join_queued
-    _join_queued = False
+    _join_queued = -2
     if _side_stream is not None:
         torch.cuda.current_stream().wait_stream(_side_stream)
     if _branch_stream is not None:
@@ -512,8 +536,9 @@ def _queue_join_at_end_of_backward():
     """Make the stream that called backward() wait for the side stream when the backward pass ends, so `.grad`
     is safe to read right after `loss.backward()` (same mechanism DDP uses for its final synchronisation)."""
     global _join_queued
-    if not _join_queued:
-        _join_queued = True
+    tid = _graph_task_id()
+    if tid < 0 or _join_queued != tid:
+        _join_queued = tid
         torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
 
 
@@ -661,6 +686,7 @@ class _Conv(torch.autograd.Function):
                     dwp = _new((splits, cop, planes * cip), dy)
                     bws = _new((splits, cop), dy) if dbp is not None else None
                 elif defer:
+                    _begin_defer()          # (before the kernel: a pass that died may have left this workspace dirty)
                     dwp = _rest_workspace(weight, (cop, planes * cip), dy)
                 else:
                     dwp = _new((cop, planes * cip), dy)
@@ -851,6 +877,8 @@ class _GroupNormAct(torch.autograd.Function):
         dbeta = sb if direct else torch.zeros_like(beta)
         red = _new((B * S * C * 2 + B * C * 2 + B * G * 2,), x)
         defer = direct and DEFER_UNPACK and not DETERMINISTIC      # the batch reduction joins the end-of-backward table launch
+        if defer:
+            _begin_defer()
         with _Prof("gn", (12.0 if add is None else 16.0) * x.numel(), f"gn-bwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)"):
             call("adm_gn_bwd_add", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
                  ptr(add), ptr(dx), ptr(dss), None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(red), B, HW, C, G,

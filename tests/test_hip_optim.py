@@ -285,3 +285,51 @@ def test_second_decoder_on_its_own_stream_matches_single_stream():
     scale = float(grads[0].abs().max())
     assert scale > 0 and bool(torch.isfinite(grads[1]).all())
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
+
+
+def test_backward_that_raises_leaves_no_stale_gradient_rows():
+    """A backward pass that raises half-way leaves queued unpack rows and dirty workspaces behind; the next pass must drop them
+    (not add them to the gradients, and not stay un-flushed): its gradients equal those of an undisturbed model."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import ops
+    from adm_amd.optim import FlatParams
+    gpu = torch.device("cuda:0")
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a):
+            return a.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    ref = _model(gpu)
+    fr = FlatParams(ref)
+    fr.zero_grad()
+    _loss(ref, gpu).backward()
+    torch.cuda.synchronize()
+
+    m = _model(gpu)
+    flat = FlatParams(m)
+    flat.zero_grad()
+    # the first encoder layer's output passes through the failing node: everything behind it runs its backward, then the pass dies
+    first = next(iter(m.model.enc.values()))
+    orig = first.forward
+    first.forward = lambda x, *a, **k: Boom.apply(orig(x, *a, **k))
+    x = fill.hash_tensor((2, 3, 32, 32), "x", 1.0).to(gpu)
+    try:
+        dx, dy = m(x, torch.tensor([0.05, 0.7], device=gpu))
+        with pytest.raises(RuntimeError):
+            ((dx * 1.5).sum() + (dy * 0.5).sum()).backward()
+    finally:
+        first.forward = orig
+    torch.cuda.synchronize()
+    assert ops._unpack_rows or ops._gn_rows            # the dead pass left rows behind
+    flat.zero_grad()
+    _loss(m, gpu).backward()
+    torch.cuda.synchronize()
+    assert not ops._unpack_rows and not ops._gn_rows
+    scale = float(fr.grad.abs().max())
+    assert float((flat.grad - fr.grad).abs().max()) <= 1e-5 * scale
