@@ -3,9 +3,11 @@
 // a = a0 + a1 + a2 exactly, six bf16 products per f32 product, f32 accumulation, error at the f32 MFMA's level).
 //
 //   per 2x2 tile of dY and the 4x4 patch of X around it:  a = A e A^T,  b = B^T d B,  m[ey][ex] = sum_tiles a[ey][ex] (x) b[ey][ex],
-//   dW = G^T m G.   As in the f32 kernel `ey` is gridDim.y: a workgroup reduces over TILES the y-combined rows
+//   dW = G^T m G.   As in the f32 kernel the pass `ey` belongs to the workgroup: it reduces over TILES the y-combined rows
 //   (r0, r0 + r1, r0 - r1, -r1)[ey] of dY and (r0 - r2, r1 + r2, r2 - r1, r1 - r3)[ey] of X through the x transforms (A e, B^T d), runs
-//   the four ex products, applies G^T along x in the epilogue and writes wx[co][ey][kx][ci]; adm_unpack_wgrad_wino2d applies G^T along y.
+//   the four ex products, applies G^T along x in the epilogue and writes wx[co][ey][kx][ci]; adm_unpack_wgrad_wino2d (or the
+//   end-of-backward adm_unpack_wgrad_table) applies G^T along y.  The grid is one-dimensional, (split, ey, tile) in split-major
+//   order behind an XCD-aware remap.
 //
 // The reduction index (tiles) is the K of the MFMA for both operands, and both arrive tile-major from HBM.  The f32 kernel
 // transposes them with 32 ds_write_b32 per thread and stage; here they stay tile-major in LDS ([tile][64 channels] bf16 rows of 192
@@ -17,8 +19,12 @@
 //   * waves 4-7 PRODUCE the dY-side operand, waves 8-11 the X-side operand: thread = (tile of the stage, 16-byte channel quad), a wave
 //     covers 4 tiles x 64 channels = four whole 256-byte runs per load instruction; loads of a stage (<= 4 of dY / 8 of X) are issued
 //     three stages ahead into one of three register sets; y combination, x transform (f32), three-term split, 12 ds_write_b64 per stage;
-//   * waves 0-3 CONSUME: 32 couts x 32 cins x 4 ex each; per stage 48 transposed fragment reads and 24 MFMAs: six products per ex plane
-//     from C = 0, then one rounded f32 add into the running totals (the long sums see rounded f32 adds, not truncating matrix adds);
+//   * waves 0-3 CONSUME: wave w owns the ex = w plane of the whole 64 x 64 tile (2 x 2 blocks of 32 x 32: every fragment feeds two
+//     block products); per stage 24 transposed fragment reads and 24 MFMAs: six products per block from C = 0, then one rounded f32
+//     add into the running totals (the long sums see rounded f32 adds, not truncating matrix adds); the four planes meet in LDS once,
+//     after the last stage, for G^T along x;
+//   * the producers run at s_setprio 3: VALU work and the bf16 MFMA of different waves do not overlap on a SIMD
+//     (tools/overlap_probe.hip), a stage costs their sum, and the producers are the longer dependency chain;
 //   * one s_barrier per stage with LDS-only counters: the producers' loads stay in flight across it.
 // Replaces the autograd weight gradient of Conv2d.forward (/root/reference/unet/uncond_unet.py:98-110).
 #include <algorithm>
