@@ -396,8 +396,8 @@ def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
 def _flush_gn_params():
     if not _gn_rows:
         return
-    # (the partial-sum buffers are fresh allocations, but the caching allocator hands out the same addresses every step: the device
-    #  table is re-uploaded -- a synchronising copy -- only when a row changed)
+    # (the partial-sum buffers and scale/shift tensors are fresh allocations: their addresses repeat only after a few steps, so a
+    #  new row set is common here -- its upload is asynchronous, from pinned memory)
     key = tuple(_gn_rows)
     ent = _gn_tables.get(key)
     if ent is None:
