@@ -132,9 +132,11 @@ def _wino_operands(weight: torch.Tensor, ent: "_Packed"):
 
 
 def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
-    """2-D Winograd operands (G g G^T, 16 planes) of a packed 3x3 entry, built on first use; refreshed by repack_all()."""
-    if ent.w2f is None:
-        global _pack_table
+    """2-D Winograd operands (G g G^T, 16 planes) of a packed 3x3 entry, built on first use; refreshed by repack_all().
+    With BF16X6 only their three-term bf16 splits are kept (and returned: conv_wino2d_x6.hip reads nothing else) -- the f32 planes
+    would be rewritten by every repack without ever being read (a third of the repack table's bytes)."""
+    global _pack_table
+    if ent.w2f is None and not (BF16X6 and ent.w2f6 is not None):
         co, ci = weight.shape[0], weight.shape[1]
         cop, cip = ceil32(co), ceil32(ci)
         w = _chk(weight.detach(), "weight")
@@ -142,10 +144,15 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
         ent.w2b = _new((16, cip, cop), w)
         call("adm_pack_weight_wino2d", ptr(w), ptr(ent.w2f), ptr(ent.w2b), co, ci, cop, cip)
         _pack_table = None
-    if BF16X6 and ent.w2f6 is None:
+    if not BF16X6:
+        return ent.w2f, ent.w2b
+    if ent.w2f6 is None:
         _split_x6(ent)
         _pack_table = None           # the one-launch repack table must learn the new destinations
-    return ent.w2f, ent.w2b
+    if ent.w2f is not None:          # (just used as the split's source, or left from a run with BF16X6 off)
+        ent.w2f = ent.w2b = None
+        _pack_table = None
+    return ent.w2f6, ent.w2b6
 
 
 GEMM_X6_MIN_M = 8192

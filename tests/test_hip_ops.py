@@ -272,9 +272,12 @@ def test_conv_x6_weights_follow_repack_all(ops, monkeypatch):
     y1 = ops.conv2d(nhwc(x), w, None)
     close(nchw(y1)[:, :96], F.conv2d(x, w.detach().cpu(), padding=1))
     assert not torch.equal(y0, y1)
+    assert pk.w2f is None            # only the splits are kept: the f32 planes would be rewritten by every repack and never read
     want = torch.empty_like(pk.w2f6)
     from adm_amd import hip as _hip
-    _hip.call("adm_split3_bf16", pk.w2f.data_ptr(), want.data_ptr(), pk.w2f.shape[1], pk.w2f.shape[2])
+    w2f, w2b = torch.empty((16, 96, 64), device=w.device), torch.empty((16, 64, 96), device=w.device)
+    _hip.call("adm_pack_weight_wino2d", w.detach().data_ptr(), w2f.data_ptr(), w2b.data_ptr(), 96, 64, 96, 64)
+    _hip.call("adm_split3_bf16", w2f.data_ptr(), want.data_ptr(), w2f.shape[1], w2f.shape[2])
     assert torch.equal(want.view(torch.int16), pk.w2f6.view(torch.int16))
 
 
