@@ -6,6 +6,7 @@ difference), which removes model construction, first-use weight packing and othe
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
@@ -14,7 +15,7 @@ short_dir, short_steps = (sys.argv[5], int(sys.argv[6])) if len(sys.argv) > 6 el
 
 
 def load(pattern):
-    return list(csv.DictReader(open(glob.glob(pattern)[0])))
+    return list(csv.DictReader(open(max(glob.glob(pattern), key=os.path.getmtime))))      # (the newest run, if several were merged)
 
 
 def cls(n):
