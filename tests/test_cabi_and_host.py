@@ -163,3 +163,67 @@ def test_warmup_iter_is_configurable():
     assert lr_lambda(99, 1e-4, 5e-6, 1000, warmup=100) == 1.0
     assert lr_lambda(49, 1e-4, 5e-6, 1000, warmup=100) == 0.5
     assert abs(lr_lambda(600, 1e-4, 5e-6, 1000, warmup=100) - 0.5 ** 0.96) < 1e-12
+
+
+def test_deferred_gradient_tables_host_logic(monkeypatch):
+    """Host side of the end-of-backward gradient tables (ops._defer_unpack / _defer_gn_param / flush_deferred_unpack), no GPU:
+    the rows and their block prefix sums, one flush per backward pass, the table cache, and the clean-up after a pass that raised."""
+    from adm_amd import ops
+    calls = []
+    monkeypatch.setattr(ops, "call", lambda name, *a: calls.append((name, a)))
+    monkeypatch.setattr(ops, "ptr", lambda t: t)
+    ops.reset_deferred_unpack()
+    monkeypatch.setattr(ops, "_rest_ws", {})
+    monkeypatch.setattr(ops, "_unpack_tables", {})
+    monkeypatch.setattr(ops, "_gn_tables", {})
+    ws1, ws2 = torch.ones(64, 9 * 32), torch.ones(32, 12 * 64)
+    ops._rest_ws[("a", 0)], ops._rest_ws[("b", 0)] = ws1, ws2
+    g1, g2 = torch.zeros(40, 24, 3, 3), torch.zeros(32, 47, 3, 3)
+    red, dgam, dbet = torch.zeros(1000), torch.zeros(96), torch.zeros(96)
+
+    class Layer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, fail):
+            ctx.fail = fail
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            ops._begin_defer()
+            ops._defer_unpack(ws1, g1, 40, 24, 9, 32, 0)            # plain 3x3 layout: 40*24*9 = 8640 items -> 5 blocks
+            ops._defer_gn_param(red, 200, None, 0, dgam, dbet, 4, 96)   # 96 channels -> 3 blocks
+            if ctx.fail:
+                raise RuntimeError("boom")
+            ops._defer_unpack(ws2, g2, 32, 47, 0, 64, 0)            # Winograd planes: 32*47*3 = 4512 items -> 3 blocks
+            return g * 2, None
+
+    x = torch.ones(3, requires_grad=True)
+    Layer.apply(x, False).sum().backward()
+    names = [c[0] for c in calls]
+    assert names == ["adm_gn_bwd_param_table", "adm_unpack_wgrad_table"]
+    gn_table, gn_rows, gn_blocks = calls[0][1]
+    assert gn_rows == 1 and gn_blocks == 3
+    assert gn_table.tolist() == [[red.data_ptr() + 800, 0, 0, dgam.data_ptr(), dbet.data_ptr(), 4, 96, 0]]
+    table, rows, blocks = calls[1][1]
+    assert rows == 2 and blocks == 5 + 3
+    t = table.tolist()
+    assert t[0][:10] == [ws1.data_ptr(), g1.data_ptr(), 40, 24, 9, 32, 0, 1, 1, 0]
+    assert t[1][:10] == [ws2.data_ptr(), g2.data_ptr(), 32, 47, 0, 64, 0, 1, 1, 5]
+    assert not ops._unpack_rows and not ops._gn_rows and not ops._unpack_keep
+    # a second pass with the same rows: one flush again, the cached tables, no new upload
+    uploads = ops.table_uploads
+    del calls[:]
+    Layer.apply(x, False).sum().backward()
+    assert [c[0] for c in calls] == ["adm_gn_bwd_param_table", "adm_unpack_wgrad_table"] and ops.table_uploads == uploads
+    assert calls[1][1][0] is table
+    # a pass that raises leaves its rows behind; the next pass drops them and re-zeroes every workspace BEFORE it queues its own
+    del calls[:]
+    with pytest.raises(RuntimeError):
+        Layer.apply(x, True).sum().backward()
+    assert len(ops._unpack_rows) == 1 and len(ops._gn_rows) == 1 and not calls
+    assert float(ws1.abs().max()) == 1.0
+    Layer.apply(x, False).sum().backward()
+    assert float(ws1.abs().max()) == 0.0 and float(ws2.abs().max()) == 0.0
+    assert [c[0] for c in calls] == ["adm_gn_bwd_param_table", "adm_unpack_wgrad_table"]
+    assert calls[1][1][1] == 2 and not ops._unpack_rows and not ops._gn_rows
+    ops.reset_deferred_unpack()
