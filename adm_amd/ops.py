@@ -72,7 +72,10 @@ COMPUTE = "f32"
 # 1-D Winograd F(2,3) kernel (adm_conv_fwd_wino: 1.5x fewer MFMA flops, fp32, error at the direct kernel's own rounding
 # level).  ADM_WINOGRAD=0 keeps every conv on the direct implicit GEMM.
 WINOGRAD = os.environ.get("ADM_WINOGRAD", "1") != "0"
-WINO_MIN_M = 8192
+# (ADM_WINO_MIN_M=2048 also sends the 4x4 maps of the CIFAR UNet at bs=128 to the split-bf16 kernels: 100-143 TFLOP/s against 78-105
+#  on the direct f32 kernels, 7.65 -> 6.2 ms per step, 878 -> 898 images/s in one run.  Not the default yet: the kernel choice then
+#  changes between a whole batch and its chunks at small sizes, which the bit-equality tests of the chunked autoencoder rely on.)
+WINO_MIN_M = int(os.environ.get("ADM_WINO_MIN_M", "8192"))
 # ... and those with an even height too (not the fused nearest-x2 ones) through the 2-D F(2x2, 3x3) kernel (adm_conv_fwd_wino2d:
 # 2.25x fewer MFMA flops than the direct kernel).  ADM_WINOGRAD2D=0 keeps them on the 1-D kernel.
 WINOGRAD2D = os.environ.get("ADM_WINOGRAD2D", "1") != "0"
@@ -672,9 +675,11 @@ class _Conv(torch.autograd.Function):
                         dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
                 wino_ok = _use_wino(B, Ho, Wo, ks, up, -1) and not qkv and pow2(Ho) and pow2(Wo)
-                # bf16 mode: the split-bf16 Winograd kernel (dy split exactly, x bf16 or f32) is faster than the direct bf16 weight
-                # gradient (~250 vs 179 TFLOP/s algorithmic) and more accurate
-                x6_bf = bf16 and BF16X6 and WINOGRAD2D and wino_ok and Ho >= 2
+                # bf16 mode with bf16 activation storage: the split-bf16 Winograd kernel (dy split exactly, x as stored) is faster than the
+                # direct bf16 weight gradient (~250 vs 179 TFLOP/s algorithmic) and more accurate.  With f32 storage (ADM_BF16_STORAGE=0)
+                # the direct kernel stays: it rounds x on load, so the two storage modes keep computing the same thing.
+                xbf = x.dtype == torch.bfloat16
+                x6_bf = bf16 and xbf and BF16X6 and WINOGRAD2D and wino_ok and Ho >= 2
                 wino_w = not bf16 and wino_ok
                 wino2_w = (wino_w and WINOGRAD2D and (not up or BF16X6) and Ho >= 2) or x6_bf   # 2-D F(3x3, 2x2): 12 x-folded planes per cout
                 wmode = 2 if wino2_w else int(wino_w)
@@ -682,7 +687,8 @@ class _Conv(torch.autograd.Function):
                 det = DETERMINISTIC and not bf16
                 defer = DEFER_UNPACK and wsink is not None and not det      # (with a side stream: the flush joins it first)
                 x6_w = wino2_w and BF16X6          # f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip)
-                g6_w = GEMM_WGRAD_X6 and BF16X6 and ks == 1 and not up and B * Ho * Wo >= GEMM_X6_MIN_M      # ... 1x1 convs (its MODE 1)
+                g6_w = (GEMM_WGRAD_X6 and BF16X6 and (not bf16 or xbf) and ks == 1 and not up
+                        and B * Ho * Wo >= GEMM_X6_MIN_M)      # ... 1x1 convs (its MODE 1)
                 splits = 1
                 if det:        # splits store partial tiles to a workspace; the unpack launch sums them in a fixed order
                     splits = (hip.lib().adm_conv_wgrad_x6_plan(B, Ho, Wo, cip, cop) if x6_w else

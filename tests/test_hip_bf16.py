@@ -63,12 +63,9 @@ def test_conv_bf16_forward_backward(ops_bf16, cin, cout, H, ks, up):
                                    atol=2e-4 * float(xr.grad.abs().max()))
     y32, x32, w32 = ref(x, w, gy)
     y32.backward(gy)
-    pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
-    if ops.BF16X6 and ops.WINOGRAD2D and ks == 3 and pow2(Ho) and ops._use_wino(B, Ho, Ho, ks, up, -1):
-        # the 3x3 weight gradient runs on the split-bf16 Winograd kernel (dy split exactly, x not rounded here): f32 accuracy
-        torch.testing.assert_close(wd.grad.cpu(), w32.grad, rtol=2e-4, atol=2e-5 * float(w32.grad.abs().max()))
-    else:
-        torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=2e-4, atol=3e-4 * float(wr.grad.abs().max()))
+    # (x is f32 here: the direct bf16 kernel, which rounds dy and x on load.  With bf16-STORED activations the 3x3 weight gradient
+    #  runs on the split-bf16 Winograd kernel instead: test_wgrad_x6_bf16_activations_equal_f32_kernel_on_rounded_x)
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=2e-4, atol=3e-4 * float(wr.grad.abs().max()))
     # (2) versus full fp32: bf16-level error only
     assert float((yh - y32.detach()).abs().max()) <= 2e-2 * float(y32.abs().max())
     assert float((wd.grad.cpu() - w32.grad).abs().max()) <= 2e-2 * float(w32.grad.abs().max())
@@ -145,7 +142,9 @@ def test_group_norm_bf16_storage_output(ops_bf16, C, H, drop, with_ss):
 def test_unet_bf16_storage_equals_rounding_on_load(ops_bf16, monkeypatch):
     """The storage mode changes WHERE the rounding happens, not what is computed: the forward outputs of the reduced UNet are
     bit-identical with ADM_BF16_STORAGE on (bf16 GroupNorm outputs read directly by the convs) and off (f32 outputs rounded in the
-    conv loaders); the parameter gradients agree to the run-to-run noise of the bf16 weight-gradient kernel's float atomics."""
+    conv loaders).  The parameter gradients agree at the bf16 level only: with stored bf16 activations the 3x3 / large 1x1 weight
+    gradients run on the split-bf16 kernels, which keep dY EXACT (three-term split), while the direct bf16 kernel of the f32-storage
+    mode rounds dY to bf16 on load."""
     ops = ops_bf16
     from adm_amd.unet.uncond_unet import EDMPrecond
     cfg = unet_ref.default_cfg(variant="uncond_unet", model_channels=64, num_blocks=1, dropout=0.0)
@@ -170,7 +169,7 @@ def test_unet_bf16_storage_equals_rounding_on_load(ops_bf16, monkeypatch):
     assert torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])
     assert len(on[2]) == len(off[2]) > 50
     for u, v in zip(on[2], off[2]):
-        assert float((u - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-3)
+        assert float((u - v).abs().max()) <= 1e-2 * max(float(v.abs().max()), 1e-3)
 
 
 @pytest.mark.parametrize("B,cin,cout,H,up,ks", [(8, 64, 96, 32, False, 3), (4, 96, 64, 16, True, 3), (16, 192, 192, 16, False, 3),
