@@ -382,8 +382,23 @@ def _defer_unpack(ws, dst, co, ci, taps, cip, qkv):
     items = co * ci * (taps if taps else 3)
     _unpack_rows.append((ws.data_ptr(), dst.data_ptr(), co, ci, taps, cip, int(qkv), 1, 1, (items + _UT_ITEMS - 1) // _UT_ITEMS))
     _unpack_keep.append((ws, dst))
+    _unpack_pending.add(ws.data_ptr())
     _note_producer_stream()
     _queue_flush()
+
+
+_unpack_pending = set()     # workspaces with a queued row: a layer applied twice in one pass must not meet its own pending tile
+_gn_pending = set()         # ... and the same for the dgamma destinations of the GroupNorm rows
+
+
+def _rest_workspace_for(weight, shape, like):
+    """The layer's zero-at-rest workspace, flushed first when a row for it is already queued (a module applied twice in one
+    forward pass: the second weight-gradient kernel may use plain stores, and two table rows with one workspace would be read,
+    added and cleared from two block ranges -- ADVICE r2)."""
+    ws = _rest_workspace(weight, shape, like)
+    if ws.data_ptr() in _unpack_pending:
+        flush_deferred_unpack()
+    return ws
 
 
 _gn_rows = []               # pending GroupNorm parameter-gradient reductions: (tot, ss, bstride, dgamma, dbeta, B, C, blocks)
@@ -396,11 +411,27 @@ table_uploads = 0           # diagnostics: host->device table copies (asynchrono
 def _defer_gn_param(red, tot_off, ss, bstride, dgamma, dbeta, B, C):
     """Queue `dgamma, dbeta += batch reduction of the per-image sums` for the end-of-backward table launch."""
     _begin_defer()
+    if dgamma.data_ptr() in _gn_pending:      # the same GroupNorm applied twice in one pass: its rows would race on dgamma / dbeta
+        flush_deferred_unpack()
     _gn_rows.append((red.data_ptr() + 4 * tot_off, 0 if ss is None else ss.data_ptr(), int(bstride), dgamma.data_ptr(),
                      dbeta.data_ptr(), B, C, (C + 31) // 32))
     _gn_keep.append((red, ss, dgamma, dbeta))
+    _gn_pending.add(dgamma.data_ptr())
     _note_producer_stream()
     _queue_flush()
+
+
+def _used_on(stream, *tensors):
+    """Tell the caching allocator that `tensors` are read by work enqueued on `stream`.  A block goes back to the pool of the
+    stream it was ALLOCATED on as soon as its last reference drops; without this mark that stream could hand it out again and
+    overwrite it while a kernel on `stream` is still reading (VERDICT r2 / ADVICE r2: the deferred GroupNorm rows are allocated
+    by backward nodes on the main or the second-decoder stream and, with a bucketed reducer, flushed from inside a
+    weight-gradient side-stream section).  A no-op for a tensor allocated on `stream` itself."""
+    if stream is None:
+        return
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(stream)
 
 
 def _flush_gn_params():
@@ -422,8 +453,13 @@ def _flush_gn_params():
         table_uploads += 1
     table, blocks = ent
     call("adm_gn_bwd_param_table", ptr(table), len(_gn_rows), blocks)
+    cur = torch.cuda.current_stream() if table.is_cuda else None
+    _used_on(cur, table)            # (a cached table may have been uploaded on another stream and can be dropped by the cache)
+    for red, ss, _dg, _db in _gn_keep:
+        _used_on(cur, red, ss)      # fresh allocations of the GroupNorm backward nodes: released right below
     _gn_rows.clear()
     _gn_keep.clear()
+    _gn_pending.clear()
 
 
 def flush_deferred_unpack():
@@ -457,8 +493,10 @@ def flush_deferred_unpack():
     table, blocks = ent
     n = len(_unpack_rows)
     _unpack_rows.clear()
-    _unpack_keep.clear()
+    _unpack_keep.clear()         # (workspaces and gradient views are persistent: nothing is released here)
+    _unpack_pending.clear()
     call("adm_unpack_wgrad_table", ptr(table), n, blocks)
+    _used_on(torch.cuda.current_stream() if table.is_cuda else None, table)
 
 
 def reset_deferred_unpack():
@@ -467,8 +505,10 @@ def reset_deferred_unpack():
     _unpack_queued = -2
     _unpack_rows.clear()
     _unpack_keep.clear()
+    _unpack_pending.clear()
     _gn_rows.clear()
     _gn_keep.clear()
+    _gn_pending.clear()
     for ws in _rest_ws.values():
         ws.zero_()
 
@@ -487,9 +527,23 @@ def _direct_grad(param):
     return None
 
 
+def _mark_uses(ctx, *idx_params):
+    """Forward side of _notify(): counts how often a directly-accumulated parameter takes part in the recorded graph, so that a
+    module applied twice in one forward pass announces its gradient after the LAST of its backward nodes, as autograd's own
+    accumulate-grad hook would (the bucketed reducer all-reduces a bucket as soon as every member has been announced)."""
+    for i, p in idx_params:
+        if p is not None and ctx.needs_input_grad[i] and getattr(p, "_adm_direct", False):
+            p._adm_uses = getattr(p, "_adm_uses", 0) + 1
+
+
 def _notify(param):
     # (a sink that READS the gradient -- the bucketed reducer when a bucket is complete -- calls flush_deferred_unpack() first:
     #  weight gradients and GroupNorm parameter gradients may still sit in their workspaces)
+    uses = getattr(param, "_adm_uses", 0)
+    if uses > 1:                       # more backward nodes of this parameter are still to come (FlatParams.zero_grad resets)
+        param._adm_uses = uses - 1
+        return
+    param._adm_uses = 0
     sink = getattr(param, "_adm_grad_sink", None)
     if sink is not None:
         sink(param)
@@ -634,6 +688,7 @@ class _Conv(torch.autograd.Function):
                 _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq, wq2,
                           pk.w2f6 if (BF16X6 and wq2 is not None) else None)
         ctx.save_for_backward(x16 if x16 is not None else x, weight, bias)      # (the carrier is not kept)
+        _mark_uses(ctx, (1, weight), (2, bias))
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
         return y
 
@@ -700,7 +755,7 @@ class _Conv(torch.autograd.Function):
                     bws = _new((splits, cop), dy) if dbp is not None else None
                 elif defer:
                     _begin_defer()          # (before the kernel: a pass that died may have left this workspace dirty)
-                    dwp = _rest_workspace(weight, (cop, planes * cip), dy)
+                    dwp = _rest_workspace_for(weight, (cop, planes * cip), dy)
                 else:
                     dwp = _new((cop, planes * cip), dy)
                 auto = -1 if defer else 0        # -1: chosen by the launcher, workspace zero on entry (no memset)
@@ -864,6 +919,7 @@ class _GroupNormAct(torch.autograd.Function):
         prof.__exit__()
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (G, S, bstride, silu, drop_p, seed)
+        _mark_uses(ctx, (1, gamma), (2, beta))
         if fork:          # second output = the input itself, for the residual branch; its gradient comes back as `dxr`
             return y, x_in
         return y

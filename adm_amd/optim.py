@@ -49,6 +49,7 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):       # keep .grad pointing into the flat buffer
+            p._adm_uses = 0                               # (ops._mark_uses / ops._notify: graph nodes still to run per parameter)
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
@@ -73,7 +74,10 @@ class BucketedGradReducer:
         self.active = dist.is_initialized() and (self.world > 1 or force)
         self.cuda = flat.grad.is_cuda
         self.side = torch.cuda.Stream() if (self.cuda and self.active) else None
-        self.main = torch.cuda.current_stream() if self.cuda else None       # the stream backward() is called on
+        # streams on which gradients of the running pass were announced (backward nodes run on the stream of their forward op:
+        # the caller's, the second decoder's, the weight-gradient side stream); a bucket's all-reduce is ordered after all of
+        # them.  Collected per pass -- NOT captured at construction: backward() may be called from any stream
+        self.streams = {}
         self.buckets = []             # (start, end, n_params)
         self.param_bucket = {}
         cap = max(1, bucket_bytes // 4)
@@ -111,6 +115,9 @@ class BucketedGradReducer:
             # the backward returned -- counting both launched every bucket twice (harmless at world size 1, a doubled
             # gradient sum at world size > 1)
             self.seen[idx] = True
+            if self.cuda:
+                st = torch.cuda.current_stream()
+                self.streams[st.cuda_stream] = st
             b = self.param_bucket[idx]
             self.pending[b] += 1
             if self.pending[b] == self.buckets[b][2]:
@@ -134,7 +141,8 @@ class BucketedGradReducer:
                     self.side.wait_stream(ops._side_stream)
                 if ops._branch_stream is not None:
                     self.side.wait_stream(ops._branch_stream)
-                self.side.wait_stream(self.main)
+                for st in self.streams.values():
+                    self.side.wait_stream(st)
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
@@ -161,6 +169,7 @@ class BucketedGradReducer:
                 self.exposed_ms += (time.perf_counter() - t0) * 1e3
                 self.finishes += 1
         self.handles = []
+        self.streams = {}
         self.pending = [0] * len(self.buckets)
         self.seen = [False] * len(self.flat.params)
 
