@@ -67,7 +67,9 @@ __global__ void precond_out_kernel(const T* __restrict__ x, const float* __restr
     long t = i / HW;
     int c = t % C;
     int b = t / C;
-    out[i] = a[b * cbs] * (float)x[i] + s[b * cbs] * f[((long)b * HW + p) * ldf + c];
+    float v = s[b * cbs] * f[((long)b * HW + p) * ldf + c];
+    if (x) v += a[b * cbs] * (float)x[i];        // (x == nullptr: the plain scaled NHWC -> NCHW transpose, adjoint of nchw_to_nhwc)
+    out[i] = v;
   }
 }
 __global__ void precond_out_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ s, long cbs,
@@ -597,7 +599,7 @@ extern "C" int adm_nchw_to_nhwc(const void* x, int x_is_f64, const float* mul, l
 
 extern "C" int adm_precond_out(const void* x, int x_is_f64, const float* f, int ldf, const float* a, const float* s,
                                long coef_bstride, float* out, int B, int C, int HW, hipStream_t stream) {
-  if (!x || !f || !a || !s || !out || B <= 0 || C <= 0 || HW <= 0 || ldf < C) return ADM_EINVAL;
+  if (!f || !s || !out || (x && !a) || B <= 0 || C <= 0 || HW <= 0 || ldf < C) return ADM_EINVAL;
   int grid = ew_grid((long)B * C * HW);
   if (x_is_f64)
     hipLaunchKernelGGL(precond_out_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)x, f, ldf, a, s, coef_bstride, out, B, C, HW);

@@ -1152,17 +1152,46 @@ def spatial_att_gate(att, qk, h, xres):
 # ------------------------------------------------------------------------------------------------
 # layout + preconditioning
 # ------------------------------------------------------------------------------------------------
+def _nchw_to_nhwc(x, mul, cpad):
+    B, C, H, W = x.shape
+    y = _new((B, H, W, cpad), x)
+    bs = 0 if (mul is None or mul.numel() == 1) else 1
+    call("adm_nchw_to_nhwc", ptr(x), int(x.dtype == torch.float64), ptr(mul), bs, ptr(y), B, C, H * W, cpad)
+    return y
+
+
+class _NchwToNhwc(torch.autograd.Function):
+    """The stem's layout change fused with c_in * x (uncond_unet.py:627-628), differentiable in x: EDMPrecond.forward returns
+    tensors that take part in autograd w.r.t. its input (uncond_unet.py:614-635; guidance-style callers differentiate through the
+    denoiser).  Backward = the scaled NHWC -> NCHW transpose of the stem conv's data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, mul, cpad):
+        ctx.save_for_backward(mul)
+        ctx.meta = (tuple(x.shape), x.dtype)
+        return _nchw_to_nhwc(x, mul, cpad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mul,) = ctx.saved_tensors
+        (B, C, H, W), dt = ctx.meta
+        dy = _chk(dy, "dy")
+        if mul is None:
+            mul = torch.ones(1, device=dy.device, dtype=_f32)
+        dx = _new((B, C, H, W), dy)
+        call("adm_precond_out", None, 0, ptr(dy), dy.shape[-1], None, ptr(mul), 0 if mul.numel() == 1 else 1, ptr(dx), B, C, H * W)
+        return (dx if dt == _f32 else dx.to(dt)), None, None
+
+
 def nchw_to_nhwc(x: torch.Tensor, mul: Optional[torch.Tensor], cpad: int) -> torch.Tensor:
     """[B,C,H,W] fp32/fp64 -> [B,H,W,cpad] fp32 scaled per batch by ``mul`` ([B] or [1])."""
     hip.require_cuda(x, "x")
     if x.dtype not in (torch.float32, torch.float64):
         x = x.to(torch.float32)
     x = x if x.is_contiguous() else x.contiguous()
-    B, C, H, W = x.shape
-    y = _new((B, H, W, cpad), x)
-    bs = 0 if (mul is None or mul.numel() == 1) else 1
-    call("adm_nchw_to_nhwc", ptr(x), int(x.dtype == torch.float64), ptr(mul), bs, ptr(y), B, C, H * W, cpad)
-    return y
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _NchwToNhwc.apply(x, None if mul is None else mul.detach(), cpad)
+    return _nchw_to_nhwc(x, mul, cpad)
 
 
 class _PrecondOut(torch.autograd.Function):
@@ -1175,19 +1204,26 @@ class _PrecondOut(torch.autograd.Function):
         cbs = 0 if a.numel() == 1 else 1
         call("adm_precond_out", ptr(x), int(x.dtype == torch.float64), ptr(f), ldf, ptr(a), ptr(s), cbs, ptr(out), B, C,
              H * W)
-        ctx.save_for_backward(s)
-        ctx.meta = (ldf, C, cbs)
+        ctx.save_for_backward(s, a)
+        ctx.meta = (ldf, C, cbs, x.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (s,) = ctx.saved_tensors
-        ldf, C, cbs = ctx.meta
+        s, a = ctx.saved_tensors
+        ldf, C, cbs, xdt = ctx.meta
         dout = _chk(dout, "dout")
         B, _, H, W = dout.shape
-        df = _new((B, H, W, ldf), dout)
-        call("adm_precond_out_bwd", ptr(dout), ptr(s), cbs, ptr(df), ldf, B, C, H * W)
-        return df, None, None, None
+        df = dx = None
+        if ctx.needs_input_grad[0]:
+            df = _new((B, H, W, ldf), dout)
+            call("adm_precond_out_bwd", ptr(dout), ptr(s), cbs, ptr(df), ldf, B, C, H * W)
+        if ctx.needs_input_grad[1]:          # the skip path c_skip * x (uncond_unet.py:631-632)
+            dx = torch.empty_like(dout)
+            call("adm_axpby_b", None, 0, ptr(dout), None, ptr(a), cbs, ptr(dx), B, dout.numel() // B)
+            if xdt != _f32:
+                dx = dx.to(xdt)
+        return df, dx, None, None
 
 
 def precond_out(f_nhwc, x_nchw, c_skip, c_out):
@@ -1204,22 +1240,29 @@ class _AxpbyB(torch.autograd.Function):
         out = torch.empty_like(y)
         cbs = 0 if s.numel() == 1 else 1
         call("adm_axpby_b", ptr(x), int(x.dtype == torch.float64), ptr(y), ptr(a), ptr(s), cbs, ptr(out), B, n)
-        ctx.save_for_backward(s)
-        ctx.cbs = cbs
+        ctx.save_for_backward(s, a)
+        ctx.cbs, ctx.xdt = cbs, x.dtype
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (s,) = ctx.saved_tensors
+        s, a = ctx.saved_tensors
         dout = _chk(dout, "dout")
         B = dout.shape[0]
-        dy = torch.empty_like(dout)
-        call("adm_axpby_b", None, 0, ptr(dout), None, ptr(s), ctx.cbs, ptr(dy), B, dout.numel() // B)
-        return dy, None, None, None
+        dy = dx = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty_like(dout)
+            call("adm_axpby_b", None, 0, ptr(dout), None, ptr(s), ctx.cbs, ptr(dy), B, dout.numel() // B)
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(dout)
+            call("adm_axpby_b", None, 0, ptr(dout), None, ptr(a), ctx.cbs, ptr(dx), B, dout.numel() // B)
+            if ctx.xdt != _f32:
+                dx = dx.to(ctx.xdt)
+        return dy, dx, None, None
 
 
 def axpby_batch(y, x, a, s):
-    """out = a[b] * x + s[b] * y (grad flows to y only)."""
+    """out = a[b] * x + s[b] * y (gradients flow to y, and to x when it requires one)."""
     return _AxpbyB.apply(y, x, a, s)
 
 

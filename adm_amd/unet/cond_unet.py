@@ -324,10 +324,10 @@ class Unet(nn.Module):
         n = len(in_out)
         self.downs = nn.ModuleList([])
         self.ups = nn.ModuleList([])
-        if self.two_decoders:
-            self.ups2 = nn.ModuleList([])
         self.relation_layers_down = nn.ModuleList([])
         self.relation_layers_up = nn.ModuleList([])
+        if self.two_decoders:           # registration order of cond_unet.py:710-714 (= the order of a reference optimiser state)
+            self.ups2 = nn.ModuleList([])
         self.relation_layers_up2 = nn.ModuleList([])
         w1, w2 = [list(w) for w in window_sizes1], [list(w) for w in window_sizes2]
         for ind, (di, do) in enumerate(in_out):

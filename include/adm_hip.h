@@ -300,7 +300,9 @@ int adm_resample2x(const float* x, float* y, int B, int H, int W, int C, int mod
  * EDMPrecond's `c_in * x` + .to(float32) (uncond_unet.py:616, 628) fused with NCHW->NHWC. */
 int adm_nchw_to_nhwc(const void* x, int x_is_f64, const float* mul, long mul_bstride, float* y, int B, int C, int HW,
                      int Cpad, hipStream_t stream);
-/* out_nchw[b,c,p] = a[b] * x_nchw[b,c,p] + s[b] * f_nhwc[b,p,c]   (D = c_skip x + c_out F, :631-632) */
+/* out_nchw[b,c,p] = a[b] * x_nchw[b,c,p] + s[b] * f_nhwc[b,p,c]   (D = c_skip x + c_out F, :631-632).
+ * x == NULL (then a may be NULL): out = s[b] * f -- the adjoint of adm_nchw_to_nhwc, i.e. dL/dx through `c_in * x` (the tensors
+ * EDMPrecond.forward returns take part in autograd w.r.t. x, uncond_unet.py:614-635). */
 int adm_precond_out(const void* x, int x_is_f64, const float* f, int ldf, const float* a, const float* s,
                     long coef_bstride, float* out, int B, int C, int HW, hipStream_t stream);
 /* backward of the two above w.r.t. f:  df_nhwc[b,p,c<C] = s[b] * dout_nchw[b,c,p], zero for c >= C */

@@ -239,17 +239,19 @@ def param_shapes(cfg):
     for i, (ci, co) in enumerate(in_out):
         resblock(f"downs.{i}.0", ci, ci); resblock(f"downs.{i}.1", ci, ci); lin_attn(f"downs.{i}.2", ci)
         conv(f"downs.{i}.3", co, ci, 4 if i < n - 1 else 3)
-    decs = ["ups", "ups2"] if cfg["two_decoders"] else ["ups"]
-    for d in decs:
+    def decoder(d):
         for i, (ci, co) in enumerate(reversed(in_out)):
             resblock(f"{d}.{i}.0", co + ci, co); resblock(f"{d}.{i}.1", co + ci, co); lin_attn(f"{d}.{i}.2", co)
             conv(f"{d}.{i}.3.1" if i < n - 1 else f"{d}.{i}.3", ci, co, 3)
+
+    decoder("ups")
     for i in range(n):
         relation(f"relation_layers_down.{i}", dims[i], dims[i], dims[i])
     rev = dims[::-1]
     for i in range(n):
         relation(f"relation_layers_up.{i}", rev[i + 1], rev[i], rev[i])
-    if cfg["two_decoders"]:
+    if cfg["two_decoders"]:            # cond_unet.py:710-714: ups2 is registered after relation_layers_up
+        decoder("ups2")
         for i in range(n):
             relation(f"relation_layers_up2.{i}", rev[i + 1], rev[i], rev[i])
     mid = dims[-1]

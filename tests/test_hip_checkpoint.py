@@ -87,5 +87,41 @@ def test_trainer_resumes_from_reference_checkpoint(tmp_path):
         assert torch.equal(tr.opt.ema[o:o + p.numel()].view(p.shape).cpu(), ck["ema"]["ema_model." + n]), n
         idx = names.index(n)
         assert torch.equal(tr.opt.v[o:o + p.numel()].view(p.shape).cpu(), ck["opt"]["state"][idx]["exp_avg_sq"]), n
-    tr.train(max_steps=2)                          # and it trains on from there
+    # the reference's 7TH STEP (train_uncond_dpm.py:264-310, ddm/ema.py:141-188) on the recorded draws: same image batch, the t and
+    # the noise the reference drew (g13: s7.t, s7.noise), one optimiser step of the resumed trainer -> the reference's loss, its
+    # pre-clip gradient norm, its learning rate, 16 parameters and their EMA shadows after opt.step() / ema.update()
+    x0 = fill.hash_tensor((2, 3, 16, 16), "ck.x0", 1.0).to(dev)
+    t7, n7 = torch.from_numpy(g["s7.t"]).to(dev), torch.from_numpy(g["s7.noise"]).to(dev)
+    seen = {}
+    orig_step = dpm.training_step
+
+    def step_on_recorded_draws(batch):
+        loss, log = orig_step(batch, t=t7, noise=n7)
+        seen.update(loss=float(loss.detach()), simple=float(log["train/loss_simple"]))
+        return loss, log
+
+    dpm.training_step = step_on_recorded_draws
+    tr.stream = iter(lambda: {"image": x0}, None)
+    lr7 = tr.lr * tr._lr_ratio(tr.step)
+    assert abs(lr7 - float(g["s7.lr"])) <= 1e-9 * float(g["s7.lr"]), (lr7, float(g["s7.lr"]))
+    before = {n: dict(dpm.named_parameters())[n].detach().reshape(-1)[:16].cpu().clone() for n in g["s7.names"]}
+    tr.train(max_steps=1)
+    del dpm.training_step
+    assert tr.step == 7 and tr.opt.step_count == 7 and tr.ema_step == int(g["s7.ema_step"]) == 7
+    assert abs(seen["loss"] - float(g["s7.loss"])) <= 1e-4 * float(g["s7.loss"]), (seen["loss"], float(g["s7.loss"]))
+    assert abs(seen["simple"] - float(g["s7.loss_simple"])) <= 1e-4 * float(g["s7.loss_simple"])
+    assert abs(tr.opt.grad_norm() - float(g["s7.grad_norm"])) <= 1e-4 * float(g["s7.grad_norm"]), (tr.opt.grad_norm(), float(g["s7.grad_norm"]))
+    params = dict(dpm.named_parameters())
+    for i, n in enumerate(g["s7.names"]):
+        n = str(n)
+        o = tr.flat.offsets[names.index(n)]
+        got_p = params[n].detach().reshape(-1)[:16].cpu()
+        got_e = tr.opt.ema[o:o + 16].cpu()
+        close(got_p, g["s7.param"][i], rtol=1e-5, atol=1e-7)
+        close(got_e, g["s7.ema"][i], rtol=1e-5, atol=1e-7)
+        # ... and the MOVE of the step itself (a resumed trainer that did nothing would pass the two lines above at lr 1e-4)
+        want_d = torch.from_numpy(g["s7.param"][i]) - before[n]
+        if float(want_d.abs().max()) > 0:
+            assert float(((got_p - before[n]) - want_d).abs().max()) <= 2e-2 * float(want_d.abs().max()) + 2e-9, n
+    tr.train(max_steps=1)                          # and it trains on from there
     assert tr.step == 8 and tr.opt.step_count == 8

@@ -389,6 +389,41 @@ def test_two_decoder_variant_vs_oracle(oc):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_two_decoder_variant_vs_reference_golden(oc, mode):
+    """... and against the REFERENCE's own vectors (g16: tools/make_golden_cond2.py imports /root/reference/unet/cond_unet.py):
+    both outputs, every parameter's gradient norm, eight sampled gradients incl. the second decoder's; the registration order of
+    the parameters (= the index order of a reference optimiser state) is the reference's."""
+    g = np.load(os.path.join(G, "g16_cond_unet_two_decoders.npz"))
+    m, cfg, sd = build(two_decoders=True)
+    assert [n for n, _ in m.state_dict().items()] == list(sd)
+    m.train(mode == "train")
+    x = fill.hash_tensor((2, 3, 32, 32), "cond.x", 1.0)
+    tt = torch.tensor([0.3, 0.85])
+    hm = [h.cuda() for h in R.cond_features(2, 32, 32)]
+    gx, gy = fill.hash_tensor((2, 3, 32, 32), "cond.gx", 1.0), fill.hash_tensor((2, 3, 32, 32), "cond.gy", 1.0)
+    y1, y2 = m(x.cuda(), tt.cuda(), hm)
+    close(y1, g[f"{mode}.x1"]); close(y2, g[f"{mode}.x2"])
+    ((y1 * gx.cuda()).sum() + (y2 * gy.cuda()).sum()).backward()
+    named = dict(m.named_parameters())
+    gmax = float(g[f"{mode}.gradnorm_max"])
+    bad = []
+    for key in g.files:
+        if key.startswith(f"{mode}.gradnorm."):
+            p = named[key[len(mode) + 10:]]
+            if not p.requires_grad:
+                continue
+            want = float(g[key])
+            got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+            if abs(got - want) > 2e-3 * want + 2e-4 * gmax:
+                bad.append((key, got, want))
+    assert not bad, bad[:8]
+    for key in g.files:
+        if key.startswith(f"{mode}.grad."):
+            name = key[len(mode) + 6:]
+            close(named[name].grad.reshape(-1)[:4096], g[key], scale=float(g[f"{mode}.gradnorm.{name}"]) / 8)
+
+
 def test_fp64_state_and_scalar_time(oc):
     """Sampling call pattern: fp64 latent, 0-dim fp64 time, batch > 1."""
     m, cfg, sd = build()

@@ -53,12 +53,15 @@ def test_precond_small_vs_golden(gpu, golden_dir, variant, use_aug):
     m.eval()
     x, sigma, aug = small_inputs(cfg)
     kw = dict(augment_labels=aug.to(gpu)) if use_aug else {}
-    dx, dy = m(x.to(gpu), sigma.to(gpu), **kw)
+    xg = x.to(gpu).requires_grad_(True)            # the denoiser is differentiable in its input too (uncond_unet.py:614-635)
+    dx, dy = m(xg, sigma.to(gpu), **kw)
     p = f"{variant}.aug{use_aug}."
     assert dx.dtype == torch.float32 and dx.shape == (2, 3, 32, 32)
     close(dx, g[p + "D_x"]); close(dy, g[p + "D_y"])
     gx, gy = fill.hash_tensor(dx.shape, "gx", 1.0).to(gpu), fill.hash_tensor(dy.shape, "gy", 1.0).to(gpu)
     ((dx * gx).sum() + (dy * gy).sum()).backward()
+    assert xg.grad is not None and xg.grad.shape == x.shape and xg.grad.dtype == torch.float32
+    close(xg.grad, g[p + "dL_dx"])                 # the reference's own dL/dx_t on the same inputs
     named = dict(m.named_parameters())
     for key in g.files:
         if key.startswith(p + "grad."):

@@ -43,6 +43,29 @@ def test_cond_unet_reduced_width_eval_and_train():
             close(upd["relation_layers_up.1.input_conv1.1.running_mean"], g["train.bn.relation_layers_up.1.input_conv1.1.running_mean"])
 
 
+def test_two_decoder_variant_vs_reference_golden():
+    """unet.cond_unet.Unet (two decoders, the class the DIV2K YAML names): tools/make_golden_cond2.py imported the reference
+    module (pytorch_lightning.LightningModule -> nn.Module at import time) and recorded its outputs and gradients (g16)."""
+    g = np.load(os.path.join(G, "g16_cond_unet_two_decoders.npz"))
+    cfg = R.default_cfg(dim=32, two_decoders=True)
+    sd = R.filled_state_dict(cfg)
+    names = list(sd)
+    assert names.index("ups.0.0.mlp.1.weight") < names.index("relation_layers_up.0.input_conv1.0.weight") < names.index("ups2.0.0.mlp.1.weight") \
+        < names.index("relation_layers_up2.0.input_conv1.0.weight")            # registration order of cond_unet.py:710-714
+    x = fill.hash_tensor((2, 3, 32, 32), "cond.x", 1.0)
+    tt = torch.tensor([0.3, 0.85])
+    hm = R.cond_features(2, 32, 32)
+    gx, gy = fill.hash_tensor((2, 3, 32, 32), "cond.gx", 1.0), fill.hash_tensor((2, 3, 32, 32), "cond.gy", 1.0)
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "time_mlp.0.W" else v.clone())
+           for k, v in sd.items()}
+    o1, o2 = R.unet_forward(sdo, cfg, x, tt, hm, training=False)
+    close(o1, g["eval.x1"]); close(o2, g["eval.x2"])
+    ((o1 * gx).sum() + (o2 * gy).sum()).backward()
+    for key in g.files:
+        if key.startswith("eval.grad."):
+            close(sdo[key[10:]].grad.reshape(-1)[:4096], g[key])
+
+
 def test_param_shapes_cover_both_variants():
     one = R.param_shapes(R.default_cfg())
     two = R.param_shapes(R.default_cfg(two_decoders=True))

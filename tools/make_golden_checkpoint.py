@@ -105,6 +105,43 @@ def main():
         g[tag + ".img"] = img.numpy()
         g[tag + ".w0"] = sd["model.model.enc.16x16_conv.weight"].reshape(-1)[:16].numpy()
     assert np.abs(g["ema.img"] - g["online.img"]).max() > 1e-6, "EMA and online weights must differ in the fixture"
+    # the reference's 7TH STEP, continued from the live objects the checkpoint was written from (Trainer.train,
+    # /root/reference/train_uncond_dpm.py:264-310: loss -> backward -> clip_grad_norm_(1.0) -> opt.step -> lr_scheduler.step ->
+    # ema.update, /root/reference/ddm/ema.py:141-188).  The reference draws t and the noise itself (ddm_const_2.py:163-170,
+    # 199-201); the same two draws are replayed here from the same seed and recorded, and the replay is checked against the
+    # reference's own call.
+    torch.manual_seed(106)
+    t7 = torch.rand(2) * (1.0 - float(dpm.eps)) + float(dpm.eps)
+    n7 = torch.randn_like(x0)
+    torch.manual_seed(106)
+    loss7, log7 = dpm.training_step({"image": x0})
+    opt.zero_grad()
+    loss7.backward()
+    lr7 = float(opt.param_groups[0]["lr"])
+    norm7 = float(torch.nn.utils.clip_grad_norm_(dpm.parameters(), 1.0))
+    opt.step(); sched.step(); ema.update()
+    names = [n for n, p in dpm.named_parameters() if p.requires_grad and p.numel() >= 16]
+    pick = names[::max(1, len(names) // 16)][:16]
+    sd7, ema7 = dpm.state_dict(), ema.state_dict()
+    g["s7.t"], g["s7.noise"] = t7.numpy(), n7.numpy()
+    g["s7.loss"] = np.array(float(loss7.detach()))
+    g["s7.loss_simple"] = np.array(float(log7["train/loss_simple"]))
+    g["s7.grad_norm"], g["s7.lr"] = np.array(norm7), np.array(lr7)
+    g["s7.names"] = np.array(pick)
+    g["s7.param"] = np.stack([sd7[n].reshape(-1)[:16].numpy() for n in pick])           # 16 parameters x their first 16 entries
+    g["s7.ema"] = np.stack([ema7["ema_model." + n].reshape(-1)[:16].numpy() for n in pick])
+    g["s7.ema_step"] = np.array(int(ema7["step"]))
+    g["s7.ema_decay"] = np.array(float(ema.get_current_decay()))
+    # the replayed draws are the reference's: p_losses on them reproduces the loss of the seeded call bit for bit
+    m = build(); m.load_state_dict(back["model"])
+    xn = m.q_sample(x_start=x0, noise=n7, t=t7, C=-x0)
+    with torch.no_grad():
+        cp, npred = m.model(xn, t7)
+    w1, w2 = ((t7 - 1) / t7) ** 2 + 1, (t7 / (1 - t7 + m.eps)) ** 2 + 1
+    chk = ((w1 * ((cp + x0) ** 2).sum([1, 2, 3]) + w2 * ((npred - n7) ** 2).sum([1, 2, 3])).sum() / 2)
+    assert abs(float(chk) - float(loss7.detach())) <= 1e-5 * abs(float(loss7.detach())), (float(chk), float(loss7.detach()))
+    print(f"7th step: loss {float(loss7.detach()):.6f}, grad norm {norm7:.6f}, lr {lr7:.4e}, ema step {int(ema7['step'])}, "
+          f"decay {float(ema.get_current_decay()):.6f}")
     g["opt.exp_avg0"] = back["opt"]["state"][0]["exp_avg"].reshape(-1)[:16].numpy()
     g["opt.step0"] = np.array(float(back["opt"]["state"][0]["step"]))
     g["n_params"] = np.array(len(back["opt"]["state"]))
