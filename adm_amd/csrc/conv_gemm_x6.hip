@@ -32,14 +32,13 @@ constexpr int GM = 128, GN = 128, GCH = 2;         // pixels x couts per workgro
 constexpr int G_IMG = GCH * 3 * 128 * 16;          // bf16 elements of one operand image of a stage: [chunk][term][128 rows][16] = 24 KB
 constexpr int G_RA = 2, G_RB = 4, G_D = 4;         // A slots, B slots, producer prefetch depth in stages
 
-__device__ __forceinline__ f32x2 g6_pk_sub(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// plain v_sub_f32 (not the packed form): next to the bf16 MFMA of the consumer wave on the same SIMD plain VALU is ~93 % hidden,
+// v_pk_add_f32 not at all (tools/overlap_probe2.hip; conv_wino2d_x6.hip)
 __device__ __forceinline__ f32x4 g6_sub4(f32x4 a, f32x4 b) {
-  const f32x2 lo = g6_pk_sub(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = g6_pk_sub(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
-  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm("v_sub_f32 %0, %1, %2" : "=v"(r[i]) : "v"(a[i]), "v"(b[i]));
+  return r;
 }
 __device__ __forceinline__ void g6_split3(const f32x4 v, u32x2& t0, u32x2& t1, u32x2& t2) {
   f32x4 h, mh;

@@ -54,15 +54,14 @@ constexpr int XT = 64, XK = 16;                    // 64 x 64 channel tile, 16 t
 constexpr int XROW = 96;                           // bf16 elements per LDS row: 64 channels + 32 of padding (192 bytes)
 constexpr int X_IMG = 4 * 3 * XK * XROW;           // one operand image of a stage: [4 ex][3 terms][16 tiles][XROW] = 36 KB
 
-__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x4 sub4x(f32x4 a, f32x4 b) {
-  const f32x2 lo = pk_sub2(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub2(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
-  return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
+// All the arithmetic next to the MFMAs is written with PLAIN (one value per lane) f32 instructions: tools/overlap_probe2.hip
+// measures v_add_f32 / v_and_b32 / v_perm_b32 of another wave 91-96 % hidden behind v_mfma_f32_32x32x16_bf16 on the same SIMD, and
+// the packed forms (v_pk_add_f32, v_pk_fma_f32) not at all -- they share the matrix pipe's data path, so "half the instructions"
+// costs the whole instruction.  The compiler packs every pair of f32 adds it sees, hence the inline assembly.
+__device__ __forceinline__ float x_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float x_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x4 add4x(f32x4 a, f32x4 b) { return f32x4{x_add(a[0], b[0]), x_add(a[1], b[1]), x_add(a[2], b[2]), x_add(a[3], b[3])}; }
+__device__ __forceinline__ f32x4 sub4x(f32x4 a, f32x4 b) { return f32x4{x_sub(a[0], b[0]), x_sub(a[1], b[1]), x_sub(a[2], b[2]), x_sub(a[3], b[3])}; }
 // v = v0 + v1 + v2 exactly, each term a bf16 (packed top halves: two dwords per term for the four channels)
 __device__ __forceinline__ void split3x(const f32x4 v, u32x2& t0, u32x2& t1, u32x2& t2) {
   f32x4 h, mh;
@@ -79,12 +78,12 @@ __device__ __forceinline__ void split3x(const f32x4 v, u32x2& t0, u32x2& t1, u32
   t2 = u32x2{__builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u),
              __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u)};
 }
-// a + sgn b, sgn = +-1 uniform (exact; one packed fma per pair -- a uniform "add or subtract" written as a conditional costs a branch per use)
+// a + sgn b, sgn = +-1 uniform (exact; one fma per value -- a uniform "add or subtract" written as a conditional costs a branch per use)
 __device__ __forceinline__ f32x4 fma4s(f32x4 a, f32x4 b, f32x2 sgn) {
-  f32x2 lo, hi;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(f32x2{b[0], b[1]}), "v"(sgn), "v"(f32x2{a[0], a[1]}));
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(f32x2{b[2], b[3]}), "v"(sgn), "v"(f32x2{a[2], a[3]}));
-  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r[i]) : "v"(b[i]), "v"(sgn[0]), "v"(a[i]));
+  return r;
 }
 __device__ __forceinline__ void store_planes(const f32x4 (&v)[4], unsigned short* l) {
 #pragma unroll
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     auto store = [&](int d, int slot) {            // y combination, x transforms, split, into slot
       if (XW_ABL & 2) return;
       if (MODE == 1) {
-        if (do_bias) bsum += (u0[d][0] + u0[d][1]) + (u0[d][2] + u0[d][3]);
+        if (do_bias) bsum = add4x(bsum, add4x(add4x(u0[d][0], u0[d][1]), add4x(u0[d][2], u0[d][3])));
         if (x_side && XBF) {
           const f32x4 w[4] = {wide4(u0[d][0]), wide4(u0[d][1]), wide4(u0[d][2]), wide4(u0[d][3])};
           store_planes(w, lb + slot * X_IMG);
@@ -242,15 +241,15 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
       if (!x_side) {
         const f32x4 e[2] = {fma4s(u0[d][0], u0[d][2], sgn), fma4s(u0[d][1], u0[d][3], sgn)};     // r0 +- r1 (an unused row was read as zeros)
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a[4] = {e[0], e[0] + e[1], sub4x(e[0], e[1]), sub4x(zero, e[1])};
-        if (do_bias) bsum += a[1];
+        const f32x4 a[4] = {e[0], add4x(e[0], e[1]), sub4x(e[0], e[1]), sub4x(zero, e[1])};
+        if (do_bias) bsum = add4x(bsum, a[1]);
         store_planes(a, la + slot * X_IMG);
         return;
       }
       f32x4 dd[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) dd[j] = fma4s(wide4(u0[d][j]), wide4(u1[d][j]), sgn);     // rows iA +- iB; the pass ey = 2 wants iB - iA: the epilogue negates
-      const f32x4 b[4] = {sub4x(dd[0], dd[2]), dd[1] + dd[2], sub4x(dd[2], dd[1]), sub4x(dd[1], dd[3])};
+      const f32x4 b[4] = {sub4x(dd[0], dd[2]), add4x(dd[1], dd[2]), sub4x(dd[2], dd[1]), sub4x(dd[1], dd[3])};
       store_planes(b, lb + slot * X_IMG);
     };
 #pragma unroll
@@ -343,8 +342,8 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][0], b[nb][1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][1], b[nb][0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][0], b[nb][0], c, 0, 0, 0);
-        tot[mb][nb] += c;
-      }
+        tot[mb][nb] += c;          // (this file is compiled WITHOUT packed-f32 instruction selection: sixteen plain v_add_f32, which run in
+      }                            //  the shadow of the next block's MFMAs, with the MFMA -> VALU wait states the compiler inserts)
   }
   if (p.dbias != nullptr && tn == 0 && ey == (MODE == 1 ? 0 : 1)) {  // the producers' bias reduction uses two more barriers
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

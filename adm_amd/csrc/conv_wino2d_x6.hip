@@ -69,36 +69,29 @@ __device__ __forceinline__ void x6_barrier() {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// a - b on a register pair in one instruction (the compiler packs f32 adds but scalarises subtractions)
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
-  const f32x2 lo = pk_sub(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
-  return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
+// (this file is compiled WITHOUT packed-f32 instruction selection -- csrc/Makefile, NOPK -- so vector adds below are plain v_add_f32 /
+//  v_sub_f32; the explicit helpers keep the producer's arithmetic plain even if that flag is dropped)
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { return a - b; }
+// PRODUCER arithmetic: plain (one-lane-one-value) f32 adds.  tools/overlap_probe2.hip: next to v_mfma_f32_32x32x16_bf16 of another
+// wave on the same SIMD, v_add_f32 / v_and_b32 / v_perm_b32 are 91-96 % hidden, the PACKED forms (v_pk_add_f32, v_pk_fma_f32) not at
+// all (0-3 %: they share the matrix pipe's data path) -- the packed form halves the instruction count and doubles the cost.  The
+// compiler packs every f32x2-shaped add it sees, hence the inline assembly.
+__device__ __forceinline__ float p_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float p_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x4 p_add4(f32x4 a, f32x4 b) { return f32x4{p_add(a[0], b[0]), p_add(a[1], b[1]), p_add(a[2], b[2]), p_add(a[3], b[3])}; }
+__device__ __forceinline__ f32x4 p_sub4(f32x4 a, f32x4 b) { return f32x4{p_sub(a[0], b[0]), p_sub(a[1], b[1]), p_sub(a[2], b[2]), p_sub(a[3], b[3])}; }
 
-__device__ __forceinline__ f32x16 sub16(f32x16 a, f32x16 b) {
-  f32x16 r;
-#pragma unroll
-  for (int i = 0; i < 16; i += 2) {
-    const f32x2 t = pk_sub(f32x2{a[i], a[i + 1]}, f32x2{b[i], b[i + 1]});
-    r[i] = t[0]; r[i + 1] = t[1];
-  }
-  return r;
-}
+__device__ __forceinline__ f32x16 sub16(f32x16 a, f32x16 b) { return a - b; }
 
 // v = v0 + v1 + v2 exactly, each term a bf16 (packed top halves: two dwords per term for the four channels)
 __device__ __forceinline__ void split3_pack(const f32x4 v, u32x2& t0, u32x2& t1, u32x2& t2) {
   f32x4 h, mh;
 #pragma unroll
   for (int i = 0; i < 4; ++i) h[i] = __uint_as_float(__float_as_uint(v[i]) & 0xFFFF0000u);
-  const f32x4 r = sub4(v, h);
+  const f32x4 r = p_sub4(v, h);
 #pragma unroll
   for (int i = 0; i < 4; ++i) mh[i] = __uint_as_float(__float_as_uint(r[i]) & 0xFFFF0000u);
-  const f32x4 r2 = sub4(r, mh);
+  const f32x4 r2 = p_sub4(r, mh);
   t0 = u32x2{__builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u),
              __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u)};
   t1 = u32x2{__builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u),
@@ -110,7 +103,7 @@ __device__ __forceinline__ void split3_pack(const f32x4 v, u32x2& t0, u32x2& t1,
 // producer: y-combined rows e[4] (one per pixel of the patch row) -> B^T along x -> three-term split -> the [ex][term] images
 __device__ __forceinline__ void x6_store(const f32x4 (&e)[4], unsigned short* la) {
   if (X6_ABL & 2) return;
-  const f32x4 v[4] = {sub4(e[0], e[2]), e[1] + e[2], sub4(e[2], e[1]), sub4(e[1], e[3])};
+  const f32x4 v[4] = {p_sub4(e[0], e[2]), p_add4(e[1], e[2]), p_sub4(e[2], e[1]), p_sub4(e[1], e[3])};
 #pragma unroll
   for (int ex = 0; ex < 4; ++ex) {
     u32x2 t0, t1, t2;
@@ -228,13 +221,13 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
       f32x4 e[4];
       if (set_ey[d] == 1) {                           // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = dA[d][j] + dB[d][j];
+        for (int j = 0; j < 4; ++j) e[j] = p_add4(dA[d][j], dB[d][j]);
       } else if (set_ey[d] == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = sub4(dB[d][j], dA[d][j]);
+        for (int j = 0; j < 4; ++j) e[j] = p_sub4(dB[d][j], dA[d][j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = sub4(dA[d][j], dB[d][j]);
+        for (int j = 0; j < 4; ++j) e[j] = p_sub4(dA[d][j], dB[d][j]);
       }
       x6_store(e, la + slot * X6_A_STAGE);
     };
@@ -320,30 +313,44 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     const unsigned short* Bb = Bs + slot_b * X6_B_STAGE + b_foff;
     if (++slot_b == X6_RB) slot_b = 0;
     const bool first = cs.cc == 0;                    // first stage of a (block, ey) group: C = 0, no accumulator clearing
-#pragma unroll
-    for (int xi = 0; xi < 4; ++xi) {
-      bf16x8 a[3], b[3];
+    // Fragment reads are issued ONE ex GROUP AHEAD of the MFMAs that use them (two register sets): left to itself the compiler
+    // reads a group's six fragments right before its six MFMAs, so every group starts with an exposed LDS round trip (~130 cycles,
+    // four times per stage) -- a read returns while the matrix pipe works only if it was issued before the chain it follows
+    // (tools/overlap_probe2.hip: ds_read_b128 interleaved with MFMAs of the same wave costs ~6 cycles each, not a latency).
+    bf16x8 fa[2][3], fb[2][3];
+    auto frag = [&](int xi, int set) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         if (X6_ABL & 16) {
-          a[k] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, (unsigned)t, 0x3f803f80u, (unsigned)xi});
-          b[k] = __builtin_bit_cast(bf16x8, u32x4{0x3f003f00u, (unsigned)k, 0x3f003f00u, (unsigned)lane});
+          fa[set][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, (unsigned)t, 0x3f803f80u, (unsigned)xi});
+          fb[set][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f003f00u, (unsigned)k, 0x3f003f00u, (unsigned)lane});
           continue;
         }
-        a[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab + (xi * 3 + k) * X6P_T * X6K));
-        b[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb + (xi * 3 + k) * X6N * X6K));
+        fa[set][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab + (xi * 3 + k) * X6P_T * X6K));
+        fb[set][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb + (xi * 3 + k) * X6N * X6K));
       }
-      if (X6_ABL & 8) continue;
-      // small products first
-      f32x16 c;
-      if (first) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], zero, 0, 0, 0);       // (wave-uniform branch)
-      else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[xi], 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-    }
+    };
+    auto products = [&](auto first_tag) {
+      frag(0, 0);
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const int cur = xi & 1;
+        if (xi < 3) frag(xi + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);            // (keeps the next group's reads above this group's chain)
+        if (X6_ABL & 8) continue;
+        const bf16x8 *a = fa[cur], *b = fb[cur];
+        // small products first
+        f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], decltype(first_tag)::value ? zero : acc[xi], 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (first) products(std::true_type{});            // (wave-uniform)
+    else products(std::false_type{});
     const int ey = cs.ey;
     const bool last = cs.cc + 1 == cs.len;
     cs.next(chunks);

@@ -1,5 +1,5 @@
 // Diagnostic micro-benchmark / check of the split-bf16 2-D Winograd weight gradient against the f32-MFMA kernel (not part of the product).
-// hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/bench_wgrad_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bwx && LD_LIBRARY_PATH=adm_amd /tmp/bwx
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops tools/bench_wgrad_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bwx && LD_LIBRARY_PATH=adm_amd /tmp/bwx
 #include "../adm_amd/csrc/conv_wgrad_x6.hip"
 #include <cstdio>
 #include <cstdlib>

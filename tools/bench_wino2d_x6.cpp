@@ -1,5 +1,5 @@
 // Diagnostic micro-benchmark for the split-bf16 2-D Winograd kernel (not part of the product).
-// hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/bench_wino2d_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bx && LD_LIBRARY_PATH=adm_amd /tmp/bx
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops tools/bench_wino2d_x6.cpp -Ladm_amd -ladm_hip -o /tmp/bx && LD_LIBRARY_PATH=adm_amd /tmp/bx
 #include "../adm_amd/csrc/conv_wino2d_x6.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +46,7 @@ int main() {
 #endif
   run(2, 8, 32, 64, true);
   run(128, 32, 384, 384, true);
-  run(128, 32, 192, 192, false);
+  run(128, 32, 192, 192, true);
   run(128, 16, 384, 384, false);
   run(128, 16, 768, 384, false);
   run(128, 8, 384, 384, true);

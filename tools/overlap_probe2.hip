@@ -58,8 +58,8 @@ __device__ __forceinline__ void valu_iter(f32x2 (&v)[8], unsigned (&u)[8], const
   }
 }
 
-template <int KIND, int NV>
-__global__ __launch_bounds__(64 * (4 + NV)) void probe_other(float* out, int iters, int mode) {
+template <int KIND, int NV, int PRIO = 0, int CHAINS = 4>
+__global__ __launch_bounds__(64 * (4 + NV)) void probe_other(float* out, int iters, int mode, const float* gsrc = nullptr) {
   __shared__ __attribute__((aligned(16))) unsigned short lds[32768];
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 32768; i += blockDim.x) lds[i] = (unsigned short)i;
@@ -69,21 +69,33 @@ __global__ __launch_bounds__(64 * (4 + NV)) void probe_other(float* out, int ite
     s16x8 av, bv;
     for (int j = 0; j < 8; ++j) { av[j] = (short)(0x3f80 + threadIdx.x + j); bv[j] = (short)(0x3f00 + j); }
     const bf16x8 a = __builtin_bit_cast(bf16x8, av), b = __builtin_bit_cast(bf16x8, bv);
-    f32x16 c[4];
-    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
+    f32x16 c[CHAINS];
+    for (int i = 0; i < CHAINS; ++i) for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
+      for (int k = 0; k < 24 / CHAINS; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[i], 0, 0, 0);
+        for (int i = 0; i < CHAINS; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[i], 0, 0, 0);
     }
     float s = 0.f;
-    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += c[i][r];
+    for (int i = 0; i < CHAINS; ++i) for (int r = 0; r < 16; ++r) s += c[i][r];
     if (s == 12345.f) out[threadIdx.x] = s;
   } else {
     if (!(mode & 2)) return;
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
     f32x2 v[8]; unsigned u[8]; u32x4 f[4];
     for (int i = 0; i < 8; ++i) { v[i] = f32x2{(float)threadIdx.x, (float)i}; u[i] = threadIdx.x * 2654435761u + i; }
+    if (KIND == 7) {          // 8 buffer_load_dwordx4 per iteration (L1/L2-resident 64 KB window), waited for once per iteration
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gsrc), 0, 1 << 20, 0x00020000);
+      for (int it = 0; it < iters; ++it) {
+        u32x4 g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          g[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((threadIdx.x * 16 + i * 8192 + (it & 7) * 65536) & 0xFFFF0), 0, 0));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] += g[i][0] ^ g[i][3];
+      }
+    } else
     for (int it = 0; it < iters; ++it) valu_iter<KIND>(v, u, lds, f);
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1] + (float)u[i];
@@ -143,11 +155,13 @@ static float timeit(F launch) {
   return ms * 1e-3f * 2.4e9f / ITERS;      // "cycles" per iteration at a nominal 2.4 GHz
 }
 
-template <int KIND, int NV>
+static float* g_src;
+template <int KIND, int NV, int PRIO = 0, int CHAINS = 4>
 static void other(const char* name) {
   float t[4];
   for (int mode = 1; mode <= 3; ++mode)
-    t[mode] = timeit([&](int it) { hipLaunchKernelGGL((probe_other<KIND, NV>), dim3(256), dim3(64 * (4 + NV)), 0, 0, g_out, it, mode); });
+    t[mode] = timeit([&](int it) { hipLaunchKernelGGL((probe_other<KIND, NV, PRIO, CHAINS>), dim3(256), dim3(64 * (4 + NV)), 0, 0, g_out, it, mode, g_src); });
+  printf("prio=%d chains=%d ", PRIO, CHAINS);
   printf("other-wave %-30s x%d waves: mfma %.0f  other %.0f  both %.0f  (sum %.0f, max %.0f) -> hidden %.0f%%\n", name, NV, t[1], t[2], t[3],
          t[1] + t[2], t[1] > t[2] ? t[1] : t[2], 100.f * (t[1] + t[2] - t[3]) / (t[1] < t[2] ? t[1] : t[2]));
 }
@@ -159,6 +173,10 @@ static void same(const char* name) {
 
 int main() {
   hipMalloc(&g_out, 1 << 16);
+  hipMalloc(&g_src, 1 << 21); hipMemset(g_src, 0, 1 << 21);
+  other<5, 4, 1>("ds_read_b128 (24)"); other<6, 4, 1>("ds_write_b64 (12)"); other<7, 4, 0>("buffer_load_b128 (8)"); other<7, 4, 1>("buffer_load_b128 (8)");
+  other<5, 4, 0, 1>("ds_read_b128 (24)"); other<6, 4, 0, 1>("ds_write_b64 (12)"); other<5, 4, 1, 1>("ds_read_b128 (24)"); other<6, 4, 1, 1>("ds_write_b64 (12)");
+  other<7, 4, 1, 1>("buffer_load_b128 (8)"); other<0, 4, 1, 1>("v_pk_add_f32 (112)"); other<1, 4, 1, 1>("v_add_f32 (112)");
   same<1, 0>("(MFMA only)");
   other<0, 4>("v_pk_add_f32 (112)"); other<1, 4>("v_add_f32 (112)"); other<2, 4>("v_and_b32 (112)"); other<3, 4>("v_perm_b32 (112)");
   other<4, 4>("v_pk_fma_f32 (112)"); other<5, 4>("ds_read_b128 (24)"); other<6, 4>("ds_write_b64 (12)");
