@@ -340,9 +340,10 @@ class AutoencoderKL(nn.Module):
         """x NCHW in [-1, 1] -> posterior (encoder_decoder.py:937-941)."""
         B, C, H, W = x.shape
         outs = []
-        for lo, hi in self._chunks(B, H, W):
-            xh = ops.nchw_to_nhwc(x[lo:hi], None, ops.ceil32(C))
-            outs.append(_conv(self.quant_conv, self.encoder(xh)))
+        with ops.batch_invariant(B):        # every image gets the same bits whatever the chunking (kernel choice by the whole batch)
+            for lo, hi in self._chunks(B, H, W):
+                xh = ops.nchw_to_nhwc(x[lo:hi], None, ops.ceil32(C))
+                outs.append(_conv(self.quant_conv, self.encoder(xh)))
         moments = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         return DiagonalGaussianDistribution(moments, self.embed_dim)
 
@@ -352,10 +353,11 @@ class AutoencoderKL(nn.Module):
         B, C, h, w = z.shape
         f = self.down_ratio
         outs = []
-        for lo, hi in self._chunks(B, h * f, w * f):
-            zh = ops.nchw_to_nhwc(z[lo:hi].to(torch.float32), None, ops.ceil32(C))
-            y = self.decoder(_conv(self.post_quant_conv, zh))
-            outs.append(y[..., :self.decoder.conv_out.out_channels].permute(0, 3, 1, 2).contiguous())
+        with ops.batch_invariant(B):
+            for lo, hi in self._chunks(B, h * f, w * f):
+                zh = ops.nchw_to_nhwc(z[lo:hi].to(torch.float32), None, ops.ceil32(C))
+                y = self.decoder(_conv(self.post_quant_conv, zh))
+                outs.append(y[..., :self.decoder.conv_out.out_channels].permute(0, 3, 1, 2).contiguous())
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     def forward(self, input, sample_posterior=True):

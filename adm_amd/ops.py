@@ -72,10 +72,10 @@ COMPUTE = "f32"
 # 1-D Winograd F(2,3) kernel (adm_conv_fwd_wino: 1.5x fewer MFMA flops, fp32, error at the direct kernel's own rounding
 # level).  ADM_WINOGRAD=0 keeps every conv on the direct implicit GEMM.
 WINOGRAD = os.environ.get("ADM_WINOGRAD", "1") != "0"
-# (ADM_WINO_MIN_M=2048 also sends the 4x4 maps of the CIFAR UNet at bs=128 to the split-bf16 kernels: 100-143 TFLOP/s against 78-105
-#  on the direct f32 kernels, 7.65 -> 6.2 ms per step, 878 -> 898 images/s in one run.  Not the default yet: the kernel choice then
-#  changes between a whole batch and its chunks at small sizes, which the bit-equality tests of the chunked autoencoder rely on.)
-WINO_MIN_M = int(os.environ.get("ADM_WINO_MIN_M", "8192"))
+# 2048 = the 4x4 maps of the CIFAR UNet at bs=128 included: 100-143 TFLOP/s on the split-bf16 kernels against 78-105 on the direct f32
+# kernels, 7.65 -> 6.2 ms per step (round 2 parked this at 8192 because the choice then differs between a batch and its chunks at small
+# sizes; callers that split a batch into passes and need identical bits now say so: batch_invariant() below).
+WINO_MIN_M = int(os.environ.get("ADM_WINO_MIN_M", "2048"))
 # ... and those with an even height too (not the fused nearest-x2 ones) through the 2-D F(2x2, 3x3) kernel (adm_conv_fwd_wino2d:
 # 2.25x fewer MFMA flops than the direct kernel).  ADM_WINOGRAD2D=0 keeps them on the 1-D kernel.
 WINOGRAD2D = os.environ.get("ADM_WINOGRAD2D", "1") != "0"
@@ -95,6 +95,31 @@ DETERMINISTIC = os.environ.get("ADM_DETERMINISTIC", "0") == "1"
 # activations"): adm_gn_fwd_bf16out writes them, adm_conv_fwd_bf16a / adm_conv_wgrad_bf16a read them directly (half the bytes, no
 # conversion pass; bit-identical to rounding on load).  The residual stream, statistics, gradients and master weights stay f32.
 BF16_STORAGE = os.environ.get("ADM_BF16_STORAGE", "1") != "0"
+
+
+# Callers that run ONE logical batch as several passes (the frozen autoencoder's <= 1 GiB chunks) need every image to get the same
+# bits whatever the chunking.  Kernel selection and split-K both look at the number of pixels in the call, so inside
+# `with batch_invariant(B_total):` the selection uses the whole batch's size and the split-K variants (whose split count depends on
+# the call's size) are not taken.
+_SELECT_BATCH = None
+
+
+class batch_invariant:
+    def __init__(self, total_batch: int):
+        self.total = int(total_batch)
+
+    def __enter__(self):
+        global _SELECT_BATCH
+        self.old, _SELECT_BATCH = _SELECT_BATCH, self.total
+        return self
+
+    def __exit__(self, *a):
+        global _SELECT_BATCH
+        _SELECT_BATCH = self.old
+
+
+def _sel_batch(B: int) -> int:
+    return B if _SELECT_BATCH is None else max(B, _SELECT_BATCH)
 
 
 def bf16_storage() -> bool:
@@ -611,7 +636,7 @@ def _queue_join_at_end_of_backward():
 # ------------------------------------------------------------------------------------------------
 def _use_wino(B, Ho, Wo, ks, up, tile) -> bool:
     """(Ho, Wo) = the grid the conv runs on; with `up` (fused nearest x2) both are even by construction."""
-    return WINOGRAD and ks == 3 and tile < 0 and (Wo & 1) == 0 and B * Ho * Wo >= WINO_MIN_M
+    return WINOGRAD and ks == 3 and tile < 0 and (Wo & 1) == 0 and _sel_batch(B) * Ho * Wo >= WINO_MIN_M
 
 
 def _use_wino2d(B, Ho, Wo, ks, up, tile) -> bool:
@@ -622,14 +647,15 @@ def _use_wino2d(B, Ho, Wo, ks, up, tile) -> bool:
 def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None, wq2=None, wq6=None):
     """fp32 conv: 2-D Winograd F(2x2,3x3) kernel when `wq2` is given, 1-D F(2,3) when `wq`, else the direct implicit GEMM;
     small-M problems get the deterministic split-K path (workspace + fixed-order reduce)."""
+    nosplit = _SELECT_BATCH is not None        # batch_invariant(): the split count depends on the call's size
     if wq2 is not None and wq6 is not None:
-        sk = hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cin_p, n_p)
+        sk = 1 if nosplit else hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cin_p, n_p)
         ws = _new((sk * B * Ho * Wo * n_p,), x) if sk > 1 else None
         call("adm_conv_fwd_wino2d_x6_up" if up else "adm_conv_fwd_wino2d_x6", ptr(x), ptr(wq6), ptr(bias), ptr(res), ptr(y), ptr(ws),
              0 if ws is None else ws.numel(), B, Ho, Wo, cin_p, cin_p, n_p, n_p, n_p, n_p)
         return
     if wq2 is not None:
-        sk = hip.lib().adm_wino2d_splitk(B, Ho, Wo, cin_p, n_p)
+        sk = 1 if nosplit else hip.lib().adm_wino2d_splitk(B, Ho, Wo, cin_p, n_p)
         ws = _new((sk * B * Ho * Wo * n_p,), x) if sk > 1 else None       # small maps: split over the input channels, fixed-order reduce
         call("adm_conv_fwd_wino2d", ptr(x), ptr(wq2), ptr(bias), ptr(res), ptr(y), ptr(ws), 0 if ws is None else ws.numel(), B, Ho, Wo,
              cin_p, cin_p, n_p, n_p, n_p, n_p)
@@ -638,7 +664,7 @@ def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None,
         call("adm_conv_fwd_wino_up" if up else "adm_conv_fwd_wino", ptr(x), ptr(wq), ptr(bias), ptr(res), ptr(y), B, Ho, Wo,
              cin_p, cin_p, n_p, n_p, n_p, n_p)
         return
-    if tile < 0:
+    if tile < 0 and not nosplit:
         sk = hip.lib().adm_conv_splitk(B * Ho * Wo, n_p, ks * ks * cin_p)
         if sk > 1:
             ws = _new((sk * B * Ho * Wo * n_p,), x)
@@ -674,7 +700,7 @@ class _Conv(torch.autograd.Function):
         wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv
         wq2 = _wino2_operands(weight, pk)[0] if (wino and _use_wino2d(B, Ho, Wo, ks, up, tile)) else None
         wq = _wino_operands(weight, pk)[0] if (wino and wq2 is None) else None
-        g6 = not use_bf16 and _use_gemm_x6(B * Ho * Wo, ks, up, cop, cip)
+        g6 = not use_bf16 and _use_gemm_x6(_sel_batch(B) * Ho * Wo, ks, up, cop, cip)
         kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
         with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                    f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):

@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sample", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the grad-accum-2 and bf16-mode side measurements of the headline line")
     ap.add_argument("--profile-only", action="store_true", help="run warmup+steps only (for rocprofv3)")
     ap.add_argument("--small", action="store_true", help="reduced-width model (debug only; result marked invalid)")
     ap.add_argument("--config", choices=["cifar", "latent", "latent-ae", "sr"], default="cifar",
@@ -415,6 +416,48 @@ def main():
         sample_ips = world * B / st
         log(f"sample({B}) took {st:.3f}s")
 
+    # ---- side measurements carried on the ONE headline line (N = 1, configs[1] only) --------------------
+    #  * gradient accumulation 2 as in the reference YAML (configs/cifar10/ddm_uncond_const_uncond_unet.yaml:52-61): one optimiser
+    #    step = two micro-batches of B images (loss / 2 each), images/s = 2 B / time per optimiser step;
+    #  * the opt-in bf16 contraction mode (BASELINE configs[2]'s per-GPU share): same model object, conv / Linear operands rounded to
+    #    bf16, everything else as in the headline.  Never part of `value`.
+    extras = None
+    if world == 1 and args.config == "cifar" and args.dtype == "f32" and not args.no_extras and not args.profile_only:
+        dpm.train()
+
+        def accum2_step(it):
+            flat.zero_grad()
+            for ga in range(2):
+                reducer.enabled = ga == 1
+                loss, _ = dpm.training_step(batches[(it + ga) & 1])
+                (loss / 2).backward()
+            reducer.finish()
+            opt.step(lr=1e-4 * lr_lambda(400000 + it, 1e-4, 5e-6, 800000), grad_scale=1.0 / world, ema_decay=None)
+
+        def timed(fn, warm, n):
+            for i in range(warm):
+                fn(i)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(warm + i)
+            barrier()
+            return (time.perf_counter() - t0) / n
+
+        n_x = max(2, min(6, args.steps // 2))
+        t_acc = timed(accum2_step, 1, n_x)
+        ops.set_compute_precision("bf16")
+        try:
+            t_bf = timed(train_step, 2, n_x)
+        finally:
+            ops.set_compute_precision("f32")
+        extras = {"grad_accum_2": {"images_per_sec": round(2 * B / t_acc, 2), "ms_per_optimizer_step": round(t_acc * 1e3, 2), "steps": n_x,
+                                   "note": "gradient_accumulate_every: 2 of the reference YAML: two micro-batches of B per optimiser step"},
+                  "bf16_mode": {"images_per_sec": round(B / t_bf, 2), "ms_per_step": round(t_bf * 1e3, 2), "steps": n_x, "dtype": "bf16",
+                                "note": "opt-in bf16 contraction mode (BASELINE configs[2] per-GPU share: bf16 MFMA operands + bf16 activation "
+                                        "storage, f32 accumulate / master weights); `python bench.py --dtype bf16` is the full line"}}
+        log(f"extras: accum-2 {extras['grad_accum_2']['images_per_sec']} images/s, bf16 mode {extras['bf16_mode']['images_per_sec']} images/s")
+
     if rank == 0:
         what = {"cifar": "CIFAR-10 32x32 uncond DDM UNet", "latent": "64x64x3-latent uncond DDM UNet (configs[3], UNet only)",
                 "latent-ae": "CelebA-HQ-256-shaped latent DDM: frozen KL-f4 AE + 64x64x3-latent UNet (configs[3])",
@@ -447,6 +490,8 @@ def main():
                         "allreduce_exposed_ms_per_step": round(reducer.exposed_ms / max(1, reducer.finishes), 3),
                         "note": "exposed = host-measured time finish() spent waiting for the all-reduce side stream after the "
                                 "backward's own kernels had drained (0 when the reducer is inactive)"}}
+        if extras is not None:
+            out["also_measured"] = extras
         if not args.no_cpu_baseline and world == 1 and args.config == "cifar":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
