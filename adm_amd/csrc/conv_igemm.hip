@@ -298,7 +298,8 @@ int splitk_plan(long M, int N, int K) {
   const int KT = K / 32;
   if (tiles > 256 || KT < 16 || (N & 3)) return 1;
   long s = 1024 / tiles;
-  if (s > 8) s = 8;
+  const long cap = KT >= 512 ? 32 : 8;        // (K >= 16384: the one GEMM over all blocks' scale/shift gradients, ops.affine_group)
+  if (s > cap) s = cap;
   if (s > KT / 8) s = KT / 8;
   return s < 2 ? 1 : (int)s;
 }

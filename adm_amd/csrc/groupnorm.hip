@@ -215,9 +215,10 @@ __global__ void gn_bwd_reduce_kernel(const float* __restrict__ part, const float
     float gp = gamma[c] * sc1;
     sm[2 * c] = gp * R1;
     sm[2 * c + 1] = gp * R2;
-    if (dss) {
-      dss[(long)b * 2 * C + c] = gamma[c] * R2 + beta[c] * R1;   // d/d scale: sum du * z,  z = xhat*gamma + beta
-      dss[(long)b * 2 * C + C + c] = R1;                          // d/d shift
+    if (dss) {   // dss rows have the stride of the ss rows (a slice of one [B][sum of 2C] buffer for all blocks: ops.affine_group)
+      const long ds = ss_bstride ? ss_bstride : 2L * C;
+      dss[(long)b * ds + c] = gamma[c] * R2 + beta[c] * R1;       // d/d scale: sum du * z,  z = xhat*gamma + beta
+      dss[(long)b * ds + C + c] = R1;                              // d/d shift
     }
   }
   __syncthreads();
@@ -523,8 +524,9 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 2)) void gn_fused_bwd_ker
     ct[2 * cl] = gp * R1;
     ct[2 * cl + 1] = gp * R2;
     if (dss) {
-      dss[(long)b * 2 * C + c] = gamma[c] * R2 + beta[c] * R1;
-      dss[(long)b * 2 * C + C + c] = R1;
+      const long ds = ss_bstride ? ss_bstride : 2L * C;
+      dss[(long)b * ds + c] = gamma[c] * R2 + beta[c] * R1;
+      dss[(long)b * ds + C + c] = R1;
     }
   }
   __syncthreads();

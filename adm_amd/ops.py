@@ -926,11 +926,16 @@ class _GroupNormAct(torch.autograd.Function):
         prof = _Prof("gn", 8.0 * x.numel(), f"gn-fwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)")
         prof.__enter__()
         ssc, bstride = None, 0
+        slot = None
         if ss is not None:
-            ssc = _chk(ss, "scale_shift")
+            slot = getattr(ss, "_adm_dss", None)          # affine_group(): this block's slice of the one dss buffer
+            if ss.dim() == 2 and ss.stride(1) == 1 and ss.stride(0) >= ss.shape[1] and ss.dtype == _f32 and ss.is_cuda:
+                ssc = ss                                  # a column slice of a wide [B, sum 2C] buffer is read in place (row stride)
+            else:
+                ssc = _chk(ss, "scale_shift")
             if ssc.shape[-1] != 2 * C or ssc.shape[0] not in (1, B):
                 raise RuntimeError(f"scale/shift shape {tuple(ssc.shape)} does not match C={C}, B={B}")
-            bstride = 0 if ssc.shape[0] == 1 else 2 * C
+            bstride = 0 if ssc.shape[0] == 1 else (ssc.stride(0) if ssc.dim() == 2 else 2 * C)
         y = torch.empty_like(x)
         if out_bf16 and C % 64 == 0:
             # bf16 storage: the VALUES go to y16; `y` is only the f32 shape / dtype carrier autograd needs between this node and the
@@ -945,6 +950,7 @@ class _GroupNormAct(torch.autograd.Function):
         prof.__exit__()
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (G, S, bstride, silu, drop_p, seed)
+        ctx.slot = slot
         _mark_uses(ctx, (1, gamma), (2, beta))
         if fork:          # second output = the input itself, for the residual branch; its gradient comes back as `dxr`
             return y, x_in
@@ -962,10 +968,17 @@ class _GroupNormAct(torch.autograd.Function):
         HW = H * W
         dx = torch.empty_like(x)
         dss = None
+        slot = ctx.slot
         if ss is not None and ctx.needs_input_grad[3]:
             if bstride == 0 and B > 1:
                 raise RuntimeError("backward through a batch-broadcast scale/shift is not supported")
-            dss = _new((B, 2 * C), x)
+            if slot is not None and bstride == slot.stride(0):
+                dss = slot               # written in place into the group's [B, sum 2C] gradient buffer (same row stride as ss)
+            else:
+                slot = None
+                if bstride not in (0, 2 * C):
+                    raise RuntimeError("a strided scale/shift needs its gradient slot (ops.affine_group)")
+                dss = _new((B, 2 * C), x)
         sg, sb = _direct_grad(gamma), _direct_grad(beta)
         direct = sg is not None and sb is not None
         dgamma = sg if direct else torch.zeros_like(gamma)
@@ -980,6 +993,9 @@ class _GroupNormAct(torch.autograd.Function):
                  int(silu), float(drop_p), seed)
         if defer:
             _defer_gn_param(red, B * S * C * 2, ss, bstride, dgamma, dbeta, B, C)
+        if slot is not None:
+            slot._adm_flag[0] = True
+            dss = None                   # (the group's backward node reads the buffer; autograd carries nothing for this edge)
         if direct:
             _notify(gamma); _notify(beta)
             return dx, None, None, dss, None, None, None, None, None, None, None
@@ -1015,6 +1031,186 @@ def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0
     out16 = bool(to_conv) and bf16_storage()
     y, xo = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), True, out16)
     return (_attach_bf16(y) if out16 else y), xo
+
+
+# ------------------------------------------------------------------------------------------------
+# all `affine` Linears of a UNet as ONE GEMM (and their gradients as two)
+# ------------------------------------------------------------------------------------------------
+# Every UNetBlock maps the same embedding [B, E] through its own Linear(E, 2 C) to the scale / shift of its second GroupNorm
+# (uncond_unet.py:167, 195-196): 57 launches of ~16 us on 128 rows forward, 57 + 57 backward plus 56 autograd additions of the
+# embedding gradient.  The packed forward operands [2C][E] of the blocks are rows of one [sum 2C][E] matrix if they sit next to
+# each other in memory -- so they are re-homed into one buffer (the per-step repack table writes them there), the scale/shift of ALL
+# blocks is one GEMM, every block reads ITS columns in place (row stride = sum 2C, adm_gn_fwd's ss_bstride), the GroupNorm backward
+# writes d scale/shift into the same columns of one gradient buffer, and the Linears' backward is one data-gradient GEMM
+# (K = sum 2C, split over K) and one weight-gradient launch whose tile rows go to the blocks' gradients through the deferred unpack
+# table.  ADM_AFFINE_GROUP=0 keeps the per-block Linears.
+AFFINE_GROUP = os.environ.get("ADM_AFFINE_GROUP", "1") != "0"
+
+
+class AffineGroup:
+    """Host-side state of the grouped Linears: layer list, column offsets, the re-homed operand buffers."""
+
+    def __init__(self, linears):
+        self.linears = list(linears)
+        w0 = self.linears[0].weight
+        self.K = w0.shape[1]
+        if self.K % 32 or any(l.weight.shape[1] != self.K or l.weight.shape[0] % 32 or l.bias is None for l in self.linears):
+            raise RuntimeError("affine_group: every Linear must map the same, 32-aligned embedding width to a 32-aligned width, with a bias")
+        self.widths = [l.weight.shape[0] for l in self.linears]
+        self.offsets = [0]
+        for n in self.widths:
+            self.offsets.append(self.offsets[-1] + n)
+        self.total = self.offsets[-1]
+        self.wcat = self.wcat_t = self.bcat = None
+        self.sig = self.sig_t = None
+        self.bias_table = None
+        self.ws_w = self.ws_b = None          # zero-at-rest weight / bias gradient tiles (deferred unpack)
+
+    def operands(self):
+        """Current [total][K] forward operand and [total] bias; re-homes the per-layer packed operands into one buffer on first use
+        (or after a parameter was replaced) and refreshes the gathered bias when a parameter changed."""
+        global _pack_table
+        dev = self.linears[0].weight.device
+        if self.wcat is None or self.wcat.device != dev:
+            self.wcat = torch.empty((self.total, self.K), device=dev, dtype=_f32)
+            self.bcat = torch.empty((self.total,), device=dev, dtype=_f32)
+            self.wcat_t = None
+            self.sig = self.sig_t = self.bias_table = None
+        sig = _pack_epoch
+        for lin, o, n in zip(self.linears, self.offsets, self.widths):
+            w, b = lin.weight, lin.bias
+            ent = packed(w, b, 1, False)
+            want = self.wcat.data_ptr() + 4 * o * self.K
+            if ent.fwd.data_ptr() != want:                  # new entry (first use, load_state_dict, ...): move its operand in
+                view = self.wcat[o:o + n]
+                view.copy_(ent.fwd)
+                ent.fwd = view
+                ent.fwd16 = None
+                _pack_table = None                          # the repack table must learn the new destination
+                self.sig = None
+            sig += w._version + b._version + (w.data_ptr() ^ b.data_ptr())
+        if sig != self.sig:
+            if self.bias_table is None or self.bias_rows != [l.bias.data_ptr() for l in self.linears]:
+                self.bias_rows = [l.bias.data_ptr() for l in self.linears]
+                rows, begin = [], 0
+                for lin, o, n in zip(self.linears, self.offsets, self.widths):
+                    blocks = (n + _UT_ITEMS - 1) // _UT_ITEMS
+                    rows.append([lin.bias.data_ptr(), self.bcat.data_ptr() + 4 * o, n, 1, 1, 1, 0, 0, 0, begin, 0, 0])
+                    begin += blocks
+                self.bias_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), begin)
+            t, n_rows, blocks = self.bias_table
+            call("adm_unpack_wgrad_table", ptr(t), n_rows, blocks)       # (as a gather: accumulate = 0, zero_src = 0)
+            self.sig = sig
+        return self.wcat, self.bcat
+
+    def transposed(self):
+        """[K][total] operand of the embedding-gradient GEMM, refreshed when the weights changed."""
+        if self.wcat_t is None:
+            self.wcat_t = torch.empty((self.K, self.total), device=self.wcat.device, dtype=_f32)
+            self.sig_t = None
+        if self.sig_t != self.sig:
+            call("adm_pack_weight", ptr(self.wcat), None, ptr(self.wcat_t), self.total, self.K, 1, self.total, self.K, 0)
+            self.sig_t = self.sig
+        return self.wcat_t
+
+
+class _AffineGroupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, grp, *params):
+        emb = _chk(emb, "emb")
+        B, K = emb.shape
+        if K != grp.K:
+            raise RuntimeError(f"affine_group: embedding has {K} channels, the Linears expect {grp.K}")
+        wcat, bcat = grp.operands()
+        out = _new((B, grp.total), emb)
+        with _Prof("igemm", 2.0 * B * grp.total * K, f"fwd-affine-group M={B} N={grp.total} K={K}"):
+            call("adm_conv_fwd", ptr(emb), ptr(wcat), ptr(bcat), None, ptr(out), B, 1, 1, K, K, grp.total, grp.total, grp.total,
+                 grp.total, 1, 0, -1)
+        ctx.save_for_backward(emb)
+        ctx.grp = grp
+        ctx.set_materialize_grads(False)
+        need = torch.is_grad_enabled() and (emb.requires_grad or any(p.requires_grad for p in params))
+        # one gradient buffer for all blocks: block i's GroupNorm backward writes d scale/shift into columns [o_i, o_i + 2 C_i) itself
+        # (ops._GroupNormAct finds its slot on the scale/shift tensor it was given) and hands autograd nothing for that edge
+        ctx.dss = _new((B, grp.total), emb) if need else None
+        ctx.flags = [[False] for _ in grp.widths]
+        grp._last = (ctx.dss, ctx.flags)              # picked up by affine_group() right after apply()
+        ctx.n_params = len(params)
+        for i, p in enumerate(params):
+            _mark_uses(ctx, (2 + i, p))
+        return tuple(out[:, o:o + n] for o, n in zip(grp.offsets, grp.widths))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (emb,) = ctx.saved_tensors
+        grp, dss = ctx.grp, ctx.dss
+        B, K = emb.shape
+        T = grp.total
+        # normally every slot was written by a GroupNorm backward and autograd delivers nothing; a gradient that did arrive through
+        # autograd (some other consumer of a slice) is added to its slot, a slot nobody wrote is zero
+        if any(g is not None for g in grads) or not all(f[0] for f in ctx.flags):
+            for (o, n), g, f in zip(zip(grp.offsets, grp.widths), grads, ctx.flags):
+                view = dss[:, o:o + n]
+                if g is not None and f[0]:
+                    view.add_(g)
+                elif g is not None:
+                    view.copy_(g)
+                elif not f[0]:
+                    view.zero_()
+        if _branch_stream is not None:       # slots written by the second decoder's GroupNorm nodes on their own stream: autograd
+            torch.cuda.current_stream().wait_stream(_branch_stream)      # orders streams only along edges that carry a tensor
+        demb = None
+        if ctx.needs_input_grad[0]:
+            wt = grp.transposed()
+            demb = _new((B, K), emb)
+            sk = hip.lib().adm_conv_splitk(B, K, T)
+            ws = _new((sk * B * K,), emb) if sk > 1 else None
+            with _Prof("igemm", 2.0 * B * T * K, f"dgrad-affine-group M={B} N={K} K={T}"):
+                call("adm_conv_fwd_ws", ptr(dss), ptr(wt), None, None, ptr(demb), ptr(ws), 0 if ws is None else ws.numel(), B, 1, 1, T, T, K,
+                     K, K, K, 1, 0)
+        params = [p for lin in grp.linears for p in (lin.weight, lin.bias)]
+        need_w = any(ctx.needs_input_grad[2:])
+        out = [None] * ctx.n_params
+        if need_w:
+            sinks = [_direct_grad(p) for p in params]
+            direct = all(s is not None for s in sinks) and DEFER_UNPACK and not DETERMINISTIC
+            if direct:
+                _begin_defer()
+                if grp.ws_w is None or grp.ws_w.device != emb.device:
+                    grp.ws_w = torch.zeros((T, K), device=emb.device, dtype=_f32)
+                    grp.ws_b = torch.zeros((T,), device=emb.device, dtype=_f32)
+                    _rest_ws[("affine_group", id(grp), "w")] = grp.ws_w      # (re-zeroed with the others after a pass that raised)
+                    _rest_ws[("affine_group", id(grp), "b")] = grp.ws_b
+                if grp.ws_w.data_ptr() in _unpack_pending:
+                    flush_deferred_unpack()
+                dwp, dbp, auto = grp.ws_w, grp.ws_b, -1
+            else:
+                dwp, dbp, auto = _new((T, K), emb), torch.zeros((T,), device=emb.device, dtype=_f32), 0
+            with _Prof("wgrad", 2.0 * B * T * K, f"wgrad-affine-group P={B} Co={T} Ci={K}"):
+                call("adm_conv_wgrad_bias", ptr(emb), ptr(dss), ptr(dwp), ptr(dbp), B, 1, 1, K, K, T, T, 1, 0, auto)
+            for i, (lin, o, n) in enumerate(zip(grp.linears, grp.offsets, grp.widths)):
+                if direct:
+                    _defer_unpack(dwp[o:o + n], sinks[2 * i], n, K, 1, K, False)
+                    _defer_unpack(dbp[o:o + n], sinks[2 * i + 1], n, 1, 1, 1, False)
+                    _notify(lin.weight); _notify(lin.bias)
+                else:      # the packed [2C][E] tile of a 1x1 layer IS its [out, in] gradient
+                    out[2 * i], out[2 * i + 1] = dwp[o:o + n], dbp[o:o + n]
+        return (demb, None, *out)
+
+
+def affine_group(emb, grp: AffineGroup):
+    """(scale/shift of block 0, of block 1, ...) = all the group's Linears applied to emb [B, E]; each result is a column slice
+    [B, 2C] (row stride = sum of all widths) that ops.group_norm_act reads in place."""
+    params = [p for lin in grp.linears for p in (lin.weight, lin.bias)]
+    outs = _AffineGroupFn.apply(emb, grp, *params)
+    dss, flags = grp._last
+    grp._last = None
+    if dss is not None:
+        for v, o, n, f in zip(outs, grp.offsets, grp.widths, flags):
+            slot = dss[:, o:o + n]
+            slot._adm_flag = f
+            v._adm_dss = slot
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------

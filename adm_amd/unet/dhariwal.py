@@ -14,6 +14,8 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -103,6 +105,9 @@ class GroupNorm(nn.Module):
         return ops.group_norm_act_fork(x, self.weight, self.bias, None, silu=silu, to_conv=to_conv)
 
 
+_AFFINE_GROUPS = weakref.WeakKeyDictionary()      # DhariwalUNet -> (ops.AffineGroup over its blocks' `affine` Linears, the blocks)
+
+
 class UNetBlock(nn.Module):
     def __init__(self, in_channels, out_channels, emb_channels, up=False, down=False, attention=False, num_heads=None,
                  channels_per_head=64, dropout=0, skip_scale=1, eps=1e-5, resample_filter=(1, 1), resample_proj=False,
@@ -129,12 +134,13 @@ class UNetBlock(nn.Module):
             self.qkv = Conv2d(out_channels, out_channels * 3, 1, qkv=True, **(init_attn if init_attn is not None else init))
             self.proj = Conv2d(out_channels, out_channels, 1, **init_zero)
 
-    def forward(self, x, emb):
+    def forward(self, x, emb, ss=None):
+        """ss: this block's scale/shift when the caller computed all blocks' `affine` Linears as one GEMM (ops.affine_group)."""
         # (to_conv: these normalised tensors go straight into a conv -- conv0 resamples first when it down-samples)
         n0, x = self.norm0.fork(x, silu=True, to_conv=not self.conv0.down)    # x feeds the normalised branch AND the residual / skip branch
         h = self.conv0(n0)
         p = self.dropout if self.training else 0.0
-        h = self.norm1(h, self.affine(emb), silu=True, drop_p=p, to_conv=True)
+        h = self.norm1(h, self.affine(emb) if ss is None else ss, silu=True, drop_p=p, to_conv=True)
         h = self.conv1(h, residual=x if self.skip is None else self.skip(x))
         if self.num_heads:
             n2, h = self.norm2.fork(h, to_conv=True)
@@ -252,23 +258,35 @@ class DhariwalUNet(nn.Module):
         emb = ops.silu(self.map_layer0(emb))
         return ops.silu(self.map_layer1(emb))
 
-    def _decode(self, dec, x, skips, emb, out_norm, out_conv, ratios=None):
+    def _decode(self, dec, x, skips, emb, out_norm, out_conv, ratios=None, ss=None):
         stack = list(skips)
         ratios = list(ratios) if ratios is not None else None
         for block in dec.values():
             if x.shape[-1] != block.in_channels:
                 r = ratios.pop() if ratios is not None else 1.0
                 x = ops.concat_channels(x, stack.pop(), r)
-            x = block(x, emb)
+            x = block(x, emb, None if ss is None else ss[block])
         return out_conv(out_norm(x, silu=True, to_conv=True))
+
+    def _scale_shifts(self, emb):
+        """{block: its scale/shift} from ONE GEMM over the `affine` Linears of every block (ops.affine_group), or None."""
+        if not ops.AFFINE_GROUP or ops.DETERMINISTIC or ops.COMPUTE != "f32" or not emb.is_cuda:
+            return None
+        grp = _AFFINE_GROUPS.get(self)          # (kept outside the module: deepcopy / state_dict / pickling see nothing of it)
+        if grp is None:
+            blocks = [b for b in self.modules() if isinstance(b, UNetBlock)]
+            grp = _AFFINE_GROUPS[self] = (ops.AffineGroup([b.affine for b in blocks]), blocks)
+        group, blocks = grp
+        return dict(zip(blocks, ops.affine_group(emb, group)))
 
     def forward(self, x, noise_labels, class_labels=None, augment_labels=None, **kwargs):
         """x: NHWC [B,H,W,32] (3 real channels).  Returns (F_x, F_y) NHWC with 32 padded channels
         (F_y is None for single-decoder variants)."""
         emb = self.embed(noise_labels, augment_labels)
+        ss = self._scale_shifts(emb)
         skips = []
         for block in self.enc.values():
-            x = block(x, emb) if isinstance(block, UNetBlock) else block(x)
+            x = block(x, emb, None if ss is None else ss[block]) if isinstance(block, UNetBlock) else block(x)
             skips.append(x)
         ratios = None
         if self.variant == "uncond_unet_sd_3":          # skip-tuning (uncond_unet_sd_3.py:547-555)
@@ -279,13 +297,13 @@ class DhariwalUNet(nn.Module):
         if s2 is not None:      # the second decoder on its own stream, concurrently with the first (ops.BRANCH_STREAM)
             main = torch.cuda.current_stream()
             with torch.cuda.stream(s2):
-                f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2)
-            f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios)
+                f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2, ss=ss)
+            f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios, ss=ss)
             main.wait_stream(s2)
             return f_x, f_y
-        f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios)
+        f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios, ss=ss)
         if self.two_decoders:
-            f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2)
+            f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2, ss=ss)
         return f_x, f_y
 
 

@@ -247,7 +247,8 @@ int adm_gn_fwd(const float* x, float* stats, double* ws, const float* gamma, con
                hipStream_t stream);
 /* Backward of adm_gn_apply.  Pass 1 reduces per (b,c): r1 = sum du, r2 = sum du*xhat into red[B][C][2]
  * (du = dy * mask * act'(u)); pass 2 writes dx and, when the pointers are non-NULL, dss[B][2C]
- * (d scale | d shift), dgamma[C], dbeta[C] (accumulated: caller zero-fills dgamma/dbeta). */
+ * (d scale | d shift; row stride = ss_bstride when that is non-zero: ss and dss may be column slices of one wide buffer),
+ * dgamma[C], dbeta[C] (accumulated: caller zero-fills dgamma/dbeta). */
 int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta, float* red,
                int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);

@@ -352,3 +352,46 @@ def test_sampler_hip_graph_replay_equals_eager(gpu, monkeypatch):
     monkeypatch.setenv("ADM_SAMPLE_GRAPH", "0")
     e3 = dpm.sample(batch_size=3, x_T=xT)
     assert torch.equal(g3, e3) and not torch.equal(g3, eager)
+
+
+def test_affine_group_equals_per_block_linears(gpu, monkeypatch):
+    """ops.affine_group: the `affine` Linears of all blocks as one GEMM (their scale/shift read in place as column slices, the
+    GroupNorm backward writing d scale/shift into one buffer, two launches for all their gradients) against the per-block Linears:
+    same outputs, same gradients for EVERY parameter -- the Linears', the embedding MLP's behind them -- and for the input; then
+    once more after the parameters changed in place and after a load_state_dict (the re-homed operands must follow)."""
+    from adm_amd import ops
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(ops, "AFFINE_GROUP", mode)
+        m, cfg, sd = build_unet("uncond_unet", gpu)
+        m.train()
+        x, sigma, aug = small_inputs(cfg)
+        outs = []
+        for rnd in range(3):
+            if rnd == 1:
+                with torch.no_grad():
+                    for n, p in m.named_parameters():
+                        if "affine" in n:
+                            p.mul_(1.25).add_(0.01)
+                ops.invalidate_packed()
+            if rnd == 2:
+                m.load_state_dict({k: (v * 0.5 if "affine" in k else v) for k, v in sd.items()})
+            m.zero_grad()
+            xg = x.to(gpu).requires_grad_(True)
+            dx, dy = m(xg, sigma.to(gpu), augment_labels=aug.to(gpu))
+            gx, gy = fill.hash_tensor(dx.shape, "gx", 1.0).to(gpu), fill.hash_tensor(dy.shape, "gy", 1.0).to(gpu)
+            ((dx * gx).sum() + (dy * gy).sum()).backward()
+            outs.append((dx.detach().clone(), dy.detach().clone(), xg.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+        with torch.no_grad():        # the sampler's call pattern: 0-dim sigma -> one embedding row for the whole batch
+            s0 = m(x.to(gpu).double(), torch.tensor(0.37, dtype=torch.float64, device=gpu))
+        res[mode] = (outs, s0)
+    for rnd in range(3):
+        a, b = res[False][0][rnd], res[True][0][rnd]
+        close(b[0], a[0], rtol=1e-5, atol=1e-6); close(b[1], a[1], rtol=1e-5, atol=1e-6)
+        close(b[2], a[2], rtol=1e-4, atol=1e-5)
+        gmax = max(float(g.double().norm()) for g in a[3].values())
+        for n, g in a[3].items():
+            err = float((b[3][n].double() - g.double()).norm() / (g.double().norm() + 1e-6 * gmax))
+            assert err <= (2e-4 if ("affine" in n or "map_" in n) else 1e-3), (rnd, n, err)
+    assert not torch.equal(res[True][0][0][0], res[True][0][1][0]) and not torch.equal(res[True][0][1][0], res[True][0][2][0])
+    close(res[True][1][0], res[False][1][0], rtol=1e-5, atol=1e-6)
