@@ -913,7 +913,7 @@ def next_dropout_seed() -> int:
 
 class _GroupNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed, groups=0, eps=1e-5, fork=False, out_bf16=False):
+    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed, groups=0, eps=1e-5, fork=False, out_bf16=False, slot=None, slot_flag=None):
         x_in = x
         x = _chk(x, "x")
         B, H, W, C = x.shape
@@ -926,9 +926,7 @@ class _GroupNormAct(torch.autograd.Function):
         prof = _Prof("gn", 8.0 * x.numel(), f"gn-fwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)")
         prof.__enter__()
         ssc, bstride = None, 0
-        slot = None
-        if ss is not None:
-            slot = getattr(ss, "_adm_dss", None)          # affine_group(): this block's slice of the one dss buffer
+        if ss is not None:           # (slot, slot_flag: affine_group()'s slice of the one dss buffer for this block + its "written" mark)
             if ss.dim() == 2 and ss.stride(1) == 1 and ss.stride(0) >= ss.shape[1] and ss.dtype == _f32 and ss.is_cuda:
                 ssc = ss                                  # a column slice of a wide [B, sum 2C] buffer is read in place (row stride)
             else:
@@ -950,7 +948,7 @@ class _GroupNormAct(torch.autograd.Function):
         prof.__exit__()
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (G, S, bstride, silu, drop_p, seed)
-        ctx.slot = slot
+        ctx.slot, ctx.slot_flag = (slot, slot_flag) if ss is not None else (None, None)
         _mark_uses(ctx, (1, gamma), (2, beta))
         if fork:          # second output = the input itself, for the residual branch; its gradient comes back as `dxr`
             return y, x_in
@@ -961,7 +959,7 @@ class _GroupNormAct(torch.autograd.Function):
         x, gamma, beta, ss, stats = ctx.saved_tensors
         G, S, bstride, silu, drop_p, seed = ctx.meta
         if dy is None:    # only the pass-through output was used
-            return dxr, None, None, None, None, None, None, None, None, None, None
+            return dxr, None, None, None, None, None, None, None, None, None, None, None, None
         dy = _chk(dy, "dy")
         add = None if dxr is None else _chk(dxr, "residual gradient")
         B, H, W, C = x.shape
@@ -994,12 +992,12 @@ class _GroupNormAct(torch.autograd.Function):
         if defer:
             _defer_gn_param(red, B * S * C * 2, ss, bstride, dgamma, dbeta, B, C)
         if slot is not None:
-            slot._adm_flag[0] = True
+            ctx.slot_flag[0] = True
             dss = None                   # (the group's backward node reads the buffer; autograd carries nothing for this edge)
         if direct:
             _notify(gamma); _notify(beta)
-            return dx, None, None, dss, None, None, None, None, None, None, None
-        return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None
+            return dx, None, None, dss, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None, None, None
 
 
 _gn_bf16_out = None      # the bf16 values of the last bf16-storage GroupNorm forward (picked up by the wrapper below)
@@ -1018,7 +1016,9 @@ def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, s
     (ddm/encoder_decoder.py:56-57).  to_conv=True promises that the ONLY consumer of the result is ops.conv2d: in the bf16-storage
     mode the values are then written as bf16 and the returned f32 tensor is an unwritten carrier (see _GroupNormAct.forward)."""
     out16 = bool(to_conv) and bf16_storage()
-    y = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), False, out16)
+    slot = getattr(scale_shift, "_adm_dss", None) if scale_shift is not None else None       # (set by affine_group())
+    y = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), False, out16,
+                            None if slot is None else slot[0], None if slot is None else slot[1])
     return _attach_bf16(y) if out16 else y
 
 
@@ -1129,7 +1129,7 @@ class _AffineGroupFn(torch.autograd.Function):
         ctx.save_for_backward(emb)
         ctx.grp = grp
         ctx.set_materialize_grads(False)
-        need = torch.is_grad_enabled() and (emb.requires_grad or any(p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)            # (grad mode is off inside forward(): ask the node, not torch.is_grad_enabled())
         # one gradient buffer for all blocks: block i's GroupNorm backward writes d scale/shift into columns [o_i, o_i + 2 C_i) itself
         # (ops._GroupNormAct finds its slot on the scale/shift tensor it was given) and hands autograd nothing for that edge
         ctx.dss = _new((B, grp.total), emb) if need else None
@@ -1207,9 +1207,7 @@ def affine_group(emb, grp: AffineGroup):
     grp._last = None
     if dss is not None:
         for v, o, n, f in zip(outs, grp.offsets, grp.widths, flags):
-            slot = dss[:, o:o + n]
-            slot._adm_flag = f
-            v._adm_dss = slot
+            v._adm_dss = (dss[:, o:o + n], f)          # (gradient slot, its "written" mark): ops.group_norm_act hands them to its node
     return outs
 
 
