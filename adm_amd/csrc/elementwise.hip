@@ -116,6 +116,15 @@ __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __rest
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
 }
+// y = a + b + c (c may be null), 16 bytes per lane: the gradient sum of a tensor with several consumers (ops.fanout)
+__global__ void add3_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, const f32x4* __restrict__ c, f32x4* __restrict__ y,
+                            long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = a[i] + b[i];
+    if (c) v += c[i];
+    y[i] = v;
+  }
+}
 __global__ void copy_channels_kernel(const float* __restrict__ src, int lds_, int src_off, float* __restrict__ dst,
                                      int ldd, int dst_off, long M, int C4, float scale, int acc) {
   long total = M * C4;
@@ -651,6 +660,13 @@ extern "C" int adm_silu_bwd(const float* x, const float* dy, float* dx, long n, 
 extern "C" int adm_add(const float* a, const float* b, float* y, long n, hipStream_t stream) {
   if (!a || !b || !y || n <= 0) return ADM_EINVAL;
   hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, a, b, y, n);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+extern "C" int adm_add3(const float* a, const float* b, const float* c, float* y, long n, hipStream_t stream) {
+  if (!a || !b || !y || n <= 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)y) & 15)) return ADM_EINVAL;
+  hipLaunchKernelGGL(add3_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(a),
+                     reinterpret_cast<const f32x4*>(b), reinterpret_cast<const f32x4*>(c), reinterpret_cast<f32x4*>(y), n / 4);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -87,6 +87,7 @@ _SIGS = {
     "adm_silu_fwd": [P, P, L, P],
     "adm_silu_bwd": [P, P, P, L, P],
     "adm_add": [P, P, P, L, P],
+    "adm_add3": [P, P, P, P, L, P],
     "adm_copy_channels": [P, I, I, P, I, I, L, I, F, I, P],
     "adm_spatial_att_fwd": [P, I, P, P, P, P, I, I, I, P],
     "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, P, I, I, I, P],

@@ -730,8 +730,13 @@ class _Conv(torch.autograd.Function):
         wsink = _direct_grad(weight) if ctx.needs_input_grad[1] else None
         need_b = bias is not None and ctx.needs_input_grad[2]
         bsink = _direct_grad(bias) if need_b else None
+        # a bias whose packed order differs from its parameter's (qkv interleave, padded couts) goes through a zero-at-rest vector and a
+        # row of the end-of-backward table (which permutes, accumulates and clears) instead of zeros + permute + autograd's add
+        b_table = (need_b and bsink is not None and not bf16 and (qkv or cop != co) and DEFER_UNPACK and not DETERMINISTIC
+                   and wsink is not None)
         side = None
-        if (SIDE_WGRAD and PROFILE is None and wsink is not None and (not need_b or (bsink is not None and not qkv and cop == co))):
+        if (SIDE_WGRAD and PROFILE is None and wsink is not None
+                and (not need_b or (bsink is not None and not qkv and cop == co) or b_table)):
             side = _wgrad_stream()
             ev = torch.cuda.Event()
             ev.record()                      # dy (and x) are complete at this point of the main stream
@@ -752,6 +757,9 @@ class _Conv(torch.autograd.Function):
                         else:
                             db = torch.zeros((co,), device=dy.device, dtype=_f32)
                             dbp = db
+                    elif b_table:
+                        _begin_defer()
+                        dbp = _rest_workspace_for(bias, (cop,), dy)
                     else:
                         dbp = torch.zeros((cop,), device=dy.device, dtype=_f32)
                 pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
@@ -834,6 +842,9 @@ class _Conv(torch.autograd.Function):
                     if not qkv and cop == co:
                         if bsink is not None:
                             _notify(bias)
+                    elif b_table:
+                        _defer_unpack(dbp, bsink, co, 1, 1, 1, qkv)
+                        _notify(bias)
                     else:
                         db = _new((co,), dy)
                         call("adm_permute_vec", ptr(dbp), ptr(db), co, co, int(qkv), 1)
@@ -1302,6 +1313,42 @@ class _Concat(torch.autograd.Function):
         call("adm_copy_channels", ptr(dy), ca + cb, 0, ptr(da), ca, 0, M, ca, 1.0, 0)
         call("adm_copy_channels", ptr(dy), ca + cb, ca, ptr(db), cb, 0, M, cb, float(scale_b), 0)
         return da, db, None
+
+
+class _Fanout(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer; backward = ONE kernel summing the gradients that arrived (autograd would add them
+    pairwise with its own elementwise kernels: two launches and six tensor passes for three consumers instead of one and four)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [_chk(g, "gradient") for g in grads if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        i = 1
+        while i < len(gs):
+            c = gs[i + 1] if i + 1 < len(gs) else None
+            out = torch.empty_like(acc)
+            if acc.numel() % 4 == 0:
+                call("adm_add3", ptr(acc), ptr(gs[i]), ptr(c), ptr(out), acc.numel())
+                i += 2
+            else:
+                call("adm_add", ptr(acc), ptr(gs[i]), ptr(out), acc.numel())
+                i += 1
+            acc = out
+        return acc, None
+
+
+def fanout(x, n: int):
+    """n aliases of x for n consumers (the gradient sum is one HIP launch); without a graph to record, x itself n times."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * max(n, 1)
+    return _Fanout.apply(x, n)
 
 
 def concat_channels(a, b, scale_b: float = 1.0):

@@ -173,11 +173,13 @@ class SpatialAtt(nn.Module):
 def _decouple(seq: nn.Sequential, x):
     """decouple(x) + x  (uncond_unet.py:500-507, 566-567)."""
     conv, sa = seq[0], seq[1]
+    x, xres = ops.fanout(x, 2)         # the conv branch and the residual
     h = ops.conv2d(x, conv.weight, conv.bias)
-    att = ops.conv2d(h, sa.map.weight, sa.map.bias)
     qk = torch.cat([sa.q_conv.weight.reshape(1), sa.q_conv.bias, sa.k_conv.weight.reshape(1), sa.k_conv.bias])
     from .. import ops_cond            # maps larger than 8x8 (a bottleneck above 4x4) take the recomputing kernel
-    return ops_cond.spatial_att_gate(att, qk, h, x)
+    h, hg = ops.fanout(h, 2)           # ... and h feeds the attention map and the gate
+    att = ops.conv2d(h, sa.map.weight, sa.map.bias)
+    return ops_cond.spatial_att_gate(att, qk, hg, xres)
 
 
 class DhariwalUNet(nn.Module):
@@ -284,26 +286,29 @@ class DhariwalUNet(nn.Module):
         (F_y is None for single-decoder variants)."""
         emb = self.embed(noise_labels, augment_labels)
         ss = self._scale_shifts(emb)
-        skips = []
+        skips, skips2 = [], []
         for block in self.enc.values():
             x = block(x, emb, None if ss is None else ss[block]) if isinstance(block, UNetBlock) else block(x)
-            skips.append(x)
+            # an encoder output feeds the next block and one concatenation per decoder: its gradient is their sum (one launch)
+            x, sk1, sk2 = ops.fanout(x, 3) if self.two_decoders else (*ops.fanout(x, 2), None)
+            skips.append(sk1); skips2.append(sk2)
         ratios = None
         if self.variant == "uncond_unet_sd_3":          # skip-tuning (uncond_unet_sd_3.py:547-555)
             n = len(skips)
             ratios = [0.5 + 0.5 * i / (n - 1) for i in range(n)][::-1]
         f_y = None
+        x, x2 = ops.fanout(x, 2) if self.two_decoders else (x, None)      # the bottleneck feeds both decouple modules
         s2 = ops.branch_stream() if (self.two_decoders and x.is_cuda) else None
         if s2 is not None:      # the second decoder on its own stream, concurrently with the first (ops.BRANCH_STREAM)
             main = torch.cuda.current_stream()
             with torch.cuda.stream(s2):
-                f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2, ss=ss)
+                f_y = self._decode(self.dec2, _decouple(self.decouple2, x2), skips2, emb, self.out_norm2, self.out_conv2, ss=ss)
             f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios, ss=ss)
             main.wait_stream(s2)
             return f_x, f_y
         f_x = self._decode(self.dec, _decouple(self.decouple1, x), skips, emb, self.out_norm, self.out_conv, ratios, ss=ss)
         if self.two_decoders:
-            f_y = self._decode(self.dec2, _decouple(self.decouple2, x), skips, emb, self.out_norm2, self.out_conv2, ss=ss)
+            f_y = self._decode(self.dec2, _decouple(self.decouple2, x2), skips2, emb, self.out_norm2, self.out_conv2, ss=ss)
         return f_x, f_y
 
 

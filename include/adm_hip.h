@@ -317,6 +317,10 @@ int adm_silu_fwd(const float* x, float* y, long n, hipStream_t stream);
 int adm_silu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t stream);
 /* y = a + b (n floats); y may alias a */
 int adm_add(const float* a, const float* b, float* y, long n, hipStream_t stream);
+/* y = a + b (+ c when non-NULL), n % 4 == 0, 16-byte aligned: the sum of the gradients autograd would otherwise add pairwise for a
+ * tensor with several consumers -- the encoder outputs feed the next block and both decoders' concatenations
+ * (uncond_unet.py:548-571). */
+int adm_add3(const float* a, const float* b, const float* c, float* y, long n, hipStream_t stream);
 /* dst[m][dst_off + c] (+)= scale * src[m][src_off + c], c < C: channel concat / slice copies
  * (torch.cat, :571, :578; `scale` carries uncond_unet_sd_3's skip-tuning ratio) */
 int adm_copy_channels(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
