@@ -38,6 +38,9 @@
 #include "../../include/adm_hip.h"
 #include <type_traits>
 
+#ifndef X6_TL
+#define X6_TL 0      // diagnostic build: per-stage timeline of one consumer and one producer wave of workgroup 0 into p.ws (tools/bench_wino2d_x6.cpp)
+#endif
 #ifndef X6_ABL
 #define X6_ABL 0     // diagnostic builds (tools/bench_wino2d_x6.cpp): 1 no A global loads, 2 no A transform / split / LDS stores, 4 no B DMA, 8 no MFMAs, 16 no LDS fragment reads
 #endif
@@ -239,11 +242,17 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if (t + d < S) {                              // (uniform; S is even, a multiple of 4 without the up-sampling)
+          const bool tl = X6_TL && p.ws && blockIdx.x == 0 && tid == 256 && t + d < 48;
+          unsigned long long* TL = reinterpret_cast<unsigned long long*>(p.ws) + 1024 + (t + d) * 4;
+          if (tl) TL[0] = __builtin_readcyclecounter();
           store(d, d & 1);
           __builtin_amdgcn_sched_barrier(0);
+          if (tl) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TL[1] = __builtin_readcyclecounter(); }
           issue(d);                                   // stages past the end read nothing (all offsets out of range)
           __builtin_amdgcn_sched_barrier(0);
+          if (tl) TL[2] = __builtin_readcyclecounter();
           x6_barrier();
+          if (tl) TL[3] = __builtin_readcyclecounter();
         }
       }
     }
@@ -303,11 +312,15 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   issue_b();
   issue_b();
   for (int t = 0; t < S; ++t) {
+    const bool tl = X6_TL && p.ws && blockIdx.x == 0 && tid == 0 && t < 48;
+    unsigned long long* TL = reinterpret_cast<unsigned long long*>(p.ws) + t * 4;
+    if (tl) TL[0] = __builtin_readcyclecounter();
     // B(t) was issued three stages ago; B(t+1) and B(t+2) (six instructions each) may still be in flight.  Plain s_barrier +
     // explicit counters: a release fence would drain the weight prefetch (vmcnt(0)).
     if (t + 2 < S) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (t + 1 < S) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tl) TL[1] = __builtin_readcyclecounter();
     if (t + 3 < S) issue_b();
     const unsigned short* Ab = As + (t & 1) * X6_A_STAGE + a_foff;
     const unsigned short* Bb = Bs + slot_b * X6_B_STAGE + b_foff;
@@ -351,6 +364,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     };
     if (first) products(std::true_type{});            // (wave-uniform)
     else products(std::false_type{});
+    if (tl) TL[2] = __builtin_readcyclecounter();
     const int ey = cs.ey;
     const bool last = cs.cc + 1 == cs.len;
     cs.next(chunks);
@@ -474,7 +488,7 @@ static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, 
   p.Mt = (int)Mt; p.N = N; p.H = H; p.W = W; p.Hh = H / 2; p.Wh = W / 2; p.Cin = Cin; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin; p.up = up ? 1 : 0;
   p.tilesN = adm_cdiv(N, X6N);
-  p.splitk = 1; p.chunks_per_split = 0; p.ws = nullptr;
+  p.splitk = 1; p.chunks_per_split = 0; p.ws = X6_TL ? ws : nullptr;
   const long yb = (long)B * H * W * ldy * 4, rb = res ? (long)B * H * W * ldr * 4 : 0;
   p.ybytes = (yb < (1L << 31) && rb < (1L << 31)) ? (int)yb : 0;
   p.rbytes = (int)rb;

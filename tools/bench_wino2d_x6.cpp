@@ -15,6 +15,9 @@ static void run(int B, int H, int Cin, int N, bool check) {
   if (wsn < (long)ny * 2 || getenv("X6_NOSPLIT")) wsn = 0;
   hipMalloc(&x, nx * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, ny * 4); hipMalloc(&y2, ny * 4); hipMalloc(&w6, nw * 6);
   if (wsn) hipMalloc(&ws, wsn * 4);
+#if X6_TL
+  if (!ws) { hipMalloc(&ws, 1 << 20); hipMemset(ws, 0, 1 << 20); }
+#endif
   if (getenv("X6_RES")) { hipMalloc(&res, ny * 4); hipMemset(res, 0, ny * 4); }
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
   adm_split3_bf16(w, w6, N, Cin, 0);
@@ -37,6 +40,15 @@ static void run(int B, int H, int Cin, int N, bool check) {
     printf("   max|x6 - f32 kernel| = %.3e (max|y| %.3e)", mx, sc);
   }
   printf("\n");
+#if X6_TL
+  if (B == 128 && H == 32 && Cin == 384) {
+    static unsigned long long h[2048]; hipMemcpy(h, ws, sizeof(h), hipMemcpyDeviceToHost);
+    printf("consumer wave 0 of workgroup 0, stages 8..31: [wait at barrier | DMA issue + fragment reads + MFMA issue | tail (transform) -> next stage start]\n");
+    for (int t = 8; t < 32; ++t) printf("  t=%2d barrier %5llu  work %5llu  to-next %5llu\n", t, h[t * 4 + 1] - h[t * 4], h[t * 4 + 2] - h[t * 4 + 1], h[(t + 1) * 4] - h[t * 4 + 2]);
+    printf("producer wave 4: [transform + split + LDS stores (lgkmcnt 0) | row-load issue | wait at barrier]\n");
+    for (int t = 8; t < 32; ++t) { const unsigned long long* q = h + 1024 + t * 4; printf("  t=%2d store %5llu  issue %5llu  barrier %5llu\n", t, q[1] - q[0], q[2] - q[1], q[3] - q[2]); }
+  }
+#endif
   hipFree(x); hipFree(w); hipFree(y); hipFree(y2); hipFree(w6);
 }
 int main() {
