@@ -532,8 +532,15 @@ extern "C" int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N) {
   const long wgs = (long)adm_cdiv((long)B * (H / 2) * (W / 2), X6P_T) * adm_cdiv(N, X6N);
   const int chunks = Cin >> 4;
   if (wgs >= 192 || chunks < 8) return 1;
-  int s = (int)(768 / wgs);                 // up to three rounds of one workgroup per CU
-  if (s > chunks / 4) s = chunks / 4;
-  if (s > 6) s = 6;
-  return s < 2 ? 1 : s;
+  // one workgroup per CU: the launch takes (rounds of 256 workgroups) x (stages of a split + ~12 stages' worth of prologue and
+  // epilogue).  Round 2 took min(768 / wgs, chunks / 4, 6) splits: 48 workgroups x 6 = 288 = a second round for 32 of them.
+  int best = 1;
+  long best_t = (wgs + 255) / 256 * (4L * chunks + 12);
+  for (int s = 2; s <= 6 && s <= chunks / 4; ++s) {
+    const int cps = ((chunks + s - 1) / s + 1) & ~1;            // (the producer double-buffers chunk pairs)
+    const int splits = (chunks + cps - 1) / cps;
+    const long t = (wgs * splits + 255) / 256 * (4L * cps + 12);
+    if (t < best_t) { best_t = t; best = s; }
+  }
+  return best;
 }

@@ -227,3 +227,37 @@ def test_deferred_gradient_tables_host_logic(monkeypatch):
     assert [c[0] for c in calls] == ["adm_gn_bwd_param_table", "adm_unpack_wgrad_table"]
     assert calls[1][1][1] == 2 and not ops._unpack_rows and not ops._gn_rows
     ops.reset_deferred_unpack()
+
+
+def test_selection_context_and_use_counts_host_logic():
+    """CPU: (1) ops.batch_invariant(): kernel selection by the WHOLE batch's pixel count, whatever the size of the pass (the frozen
+    autoencoder's chunks must get the bits of the unchunked call); (2) ops._mark_uses / ops._notify: a parameter that takes part in
+    the graph twice is announced to its gradient sink once, by its LAST backward node, and FlatParams.zero_grad resets the count."""
+    from adm_amd import ops
+
+    class Ctx:
+        needs_input_grad = (True, True, True)
+
+    assert ops._use_wino(1, 32, 32, 3, False, -1) == (1024 >= ops.WINO_MIN_M)
+    with ops.batch_invariant(8):
+        assert ops._use_wino(1, 32, 32, 3, False, -1) == ops._use_wino(8, 32, 32, 3, False, -1) == (8192 >= ops.WINO_MIN_M)
+        assert ops._sel_batch(2) == 8 and ops._sel_batch(16) == 16
+        with ops.batch_invariant(32):
+            assert ops._sel_batch(2) == 32
+        assert ops._sel_batch(2) == 8
+    assert ops._sel_batch(2) == 2
+    p = torch.nn.Parameter(torch.zeros(4))
+    p._adm_direct = True
+    heard = []
+    p._adm_grad_sink = lambda q: heard.append(q)
+    ops._mark_uses(Ctx, (1, p)); ops._mark_uses(Ctx, (1, p)); ops._mark_uses(Ctx, (2, None))
+    assert p._adm_uses == 2
+    ops._notify(p)
+    assert heard == [] and p._adm_uses == 1
+    ops._notify(p)
+    assert heard == [p] and p._adm_uses == 0
+    ops._notify(p)                                   # (a use that was never counted, e.g. recorded before FlatParams existed)
+    assert heard == [p, p]
+    q = torch.nn.Parameter(torch.zeros(4))           # not a direct-gradient parameter: never counted
+    ops._mark_uses(Ctx, (1, q))
+    assert not hasattr(q, "_adm_uses")

@@ -333,3 +333,68 @@ def test_backward_that_raises_leaves_no_stale_gradient_rows():
     assert not ops._unpack_rows and not ops._gn_rows
     scale = float(fr.grad.abs().max())
     assert float((flat.grad - fr.grad).abs().max()) <= 1e-5 * scale
+
+
+def test_module_applied_twice_with_direct_gradients_and_a_reducer_sink():
+    """A conv and a GroupNorm applied TWICE in one forward pass, gradients accumulated directly into the flat buffer through the
+    deferred tables: the second weight-gradient kernel must not meet its own pending tile (plain stores with one split),
+    the two GroupNorm rows must not race on dgamma / dbeta, and a gradient sink (the bucketed reducer's hook) hears about each
+    parameter ONCE, after its last backward node -- autograd's accumulate-grad semantics."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.nn as nn
+    from adm_amd import ops
+    from adm_amd.optim import FlatParams
+    gpu = torch.device("cuda:0")
+
+    class Twice(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Parameter(fill.hash_tensor((64, 64, 3, 3), "tw.w", 0.05))
+            self.b = nn.Parameter(fill.hash_tensor((64,), "tw.b", 0.1))
+            self.g = nn.Parameter(1 + fill.hash_tensor((64,), "tw.g", 0.1))
+            self.be = nn.Parameter(fill.hash_tensor((64,), "tw.be", 0.1))
+
+        def forward(self, x):
+            for _ in range(2):
+                x = ops.conv2d(ops.group_norm_act(x, self.g, self.be, None, silu=True), self.w, self.b)
+            return x
+
+    x = fill.hash_tensor((4, 16, 16, 64), "tw.x", 1.0).to(gpu)
+    gy = fill.hash_tensor((4, 16, 16, 64), "tw.gy", 1.0).to(gpu)
+    ref = Twice().to(gpu)
+    (ref(x) * gy).sum().backward()                 # plain autograd: every use returns its own gradient, autograd adds them
+    m = Twice().to(gpu)
+    flat = FlatParams(m)
+    heard = []
+    for p in m.parameters():
+        p._adm_grad_sink = (lambda q, _p=p: heard.append(id(_p)))
+    for _ in range(2):
+        flat.zero_grad()
+        heard.clear()
+        (m(x) * gy).sum().backward()
+    torch.cuda.synchronize()
+    assert sorted(heard) == sorted(id(p) for p in m.parameters()), "each parameter is announced once, after its last use"
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()), msg=n)
+
+
+def test_fanout_sums_the_gradients_of_all_consumers():
+    """ops.fanout: n aliases of a tensor; backward = one add3 launch per three gradients (odd sizes: the two-input kernel)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adm_amd import ops
+    gpu = torch.device("cuda:0")
+    for shape, n in (((2, 8, 8, 32), 3), ((2, 8, 8, 32), 2), ((3, 5, 7), 4), ((2, 4, 4, 64), 5)):
+        x = fill.hash_tensor(shape, "fan.x", 1.0).to(gpu).requires_grad_(True)
+        ws = [fill.hash_tensor(shape, f"fan.w{i}", 1.0).to(gpu) for i in range(n)]
+        outs = ops.fanout(x, n)
+        assert len(outs) == n and all(o.data_ptr() == x.data_ptr() for o in outs)
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        torch.testing.assert_close(x.grad, sum(ws), rtol=1e-6, atol=1e-6)
+    with torch.no_grad():
+        assert all(o is x for o in ops.fanout(x, 3))
+    y = fill.hash_tensor((2, 8, 8, 32), "fan.y", 1.0).to(gpu).requires_grad_(True)
+    a, b, c = ops.fanout(y, 3)                     # a consumer that never contributes a gradient
+    ((a * 2).sum() + (c * 3).sum()).backward()
+    torch.testing.assert_close(y.grad, torch.full_like(y, 5.0))
