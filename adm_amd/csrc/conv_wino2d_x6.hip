@@ -53,6 +53,7 @@ struct X6P {
   int splitk, chunks_per_split; float* ws;
   int ybytes, rbytes;                  // > 0: y / res fit 32-bit byte offsets (branch-free buffer epilogue)
   int up;                              // 1: x is [B][H/2][W/2][ldx] and the conv runs on its nearest x2 up-sampling (Conv2d(up=True))
+  const float* amax_x; float wscale;   // fp16 format only: device scalar >= max |x|; the weights' (power-of-two) scale
 };
 
 typedef __attribute__((address_space(3))) void x6_lds_void;
@@ -60,8 +61,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int X6P_T = 64, X6N = 64, X6K = 16;      // tiles x couts x K step
-constexpr int X6_A_STAGE = 4 * 3 * X6P_T * X6K;    // bf16 elements per A sub-stage image (24 KB)
-constexpr int X6_B_STAGE = 4 * 3 * X6N * X6K;
+[[maybe_unused]] constexpr int X6_A_STAGE = 4 * 3 * X6P_T * X6K;    // bf16 elements per A sub-stage image (24 KB; the bf16 format)
+[[maybe_unused]] constexpr int X6_B_STAGE = 4 * 3 * X6N * X6K;
+// Number formats of the split (template parameter FMT of the kernel):
+//   0  a = a0 + a1 + a2, three bf16 terms by truncation, exact; a b from SIX products (small ones first, the three below 2^-24 dropped).
+//      Needs nothing but the operands.
+//   1  s a = h0 + h1, two fp16 terms by round-to-nearest, |s a - h0 - h1| <= 2^-24 |s a| while h1 is a normal fp16 number and
+//      <= 2^-25 absolutely below that; a b from THREE products (h1 h1' <= 2^-24 |a b| dropped).  s is a power of two chosen from an
+//      upper bound of max |a| so that the Winograd input transform (sums of four values) stays inside the fp16 range: the caller
+//      passes that bound as a device scalar (the GroupNorm kernel that produced the activation wrote it).  Against fp64 it is as
+//      accurate as format 0 on normal, all-positive, heavy-tailed and single-outlier data (tools/fp16x3_accuracy.py; on the GPU:
+//      tests/test_hip_ops.py::test_conv_h3_error_vs_fp64) and halves the MFMAs, the fragment reads, the split stores and the weight
+//      DMA of a stage: 1.25 -> 1.02 ms on 128 x 32 x 32 x 384 -> 384 (tools/exp_wino2d_h3.hip).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int FMT> struct X6Fmt {
+  static constexpr int TERMS = FMT ? 2 : 3;
+  static constexpr int A_STAGE = 4 * TERMS * X6P_T * X6K;
+  static constexpr int B_STAGE = 4 * TERMS * X6N * X6K;
+  static constexpr int DMA_PER_WAVE = 2 * TERMS;     // 4 ex x TERMS images x two 32-row halves / 4 consumer waves
+};
+// power-of-two scale that puts 4 * amax below the fp16 range (65504): s * amax <= 16000
+__device__ __host__ inline float h3_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3e38f)) return 1.f;
+  int e;
+  frexpf(16000.f / amax, &e);                         // 16000 / amax = m 2^e, m in [0.5, 1)
+  return ldexpf(1.f, e - 1);
+}
 constexpr int X6_RA = 2, X6_RB = 4;                // ring depths (weights three stages ahead: a DMA queues behind the producers' loads)
 
 // LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), NOT for its global loads
@@ -103,6 +129,30 @@ __device__ __forceinline__ void split3_pack(const f32x4 v, u32x2& t0, u32x2& t1,
              __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u)};
 }
 
+// v * s = h0 + h1 (two fp16 terms, round to nearest), four channels -> two dwords per term
+__device__ __forceinline__ void split2_pack(const f32x4 v, float s, u32x2& t0, u32x2& t1) {
+  _Float16 h0[4], h1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float vs = v[i] * s;
+    h0[i] = (_Float16)vs;
+    h1[i] = (_Float16)(vs - (float)h0[i]);
+  }
+  t0 = u32x2{__builtin_bit_cast(unsigned, f16x2{h0[0], h0[1]}), __builtin_bit_cast(unsigned, f16x2{h0[2], h0[3]})};
+  t1 = u32x2{__builtin_bit_cast(unsigned, f16x2{h1[0], h1[1]}), __builtin_bit_cast(unsigned, f16x2{h1[2], h1[3]})};
+}
+__device__ __forceinline__ void h3_store(const f32x4 (&e)[4], unsigned short* la, float s) {
+  if (X6_ABL & 2) return;
+  const f32x4 v[4] = {p_sub4(e[0], e[2]), p_add4(e[1], e[2]), p_sub4(e[2], e[1]), p_sub4(e[1], e[3])};
+#pragma unroll
+  for (int ex = 0; ex < 4; ++ex) {
+    u32x2 t0, t1;
+    split2_pack(v[ex], s, t0, t1);
+    *reinterpret_cast<u32x2*>(la + (ex * 2 + 0) * X6P_T * X6K) = t0;
+    *reinterpret_cast<u32x2*>(la + (ex * 2 + 1) * X6P_T * X6K) = t1;
+  }
+}
+
 // producer: y-combined rows e[4] (one per pixel of the patch row) -> B^T along x -> three-term split -> the [ex][term] images
 __device__ __forceinline__ void x6_store(const f32x4 (&e)[4], unsigned short* la) {
   if (X6_ABL & 2) return;
@@ -138,10 +188,15 @@ struct X6Seq {
   }
 };
 
+template <int FMT>
 __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
+  using F = X6Fmt<FMT>;
+  constexpr int TERMS = F::TERMS;
+  float sa = 1.f, inv_scale = 1.f;                     // fp16 format: operand scale and the factor that undoes both scales in the epilogue
+  if (FMT) { sa = h3_scale(*p.amax_x); inv_scale = 1.f / (sa * p.wscale); }
   extern __shared__ __attribute__((aligned(16))) unsigned short smem6[];
   unsigned short* As = smem6;                          // [X6_RA][4 ex][3 terms][X6P_T][X6K]
-  unsigned short* Bs = smem6 + X6_RA * X6_A_STAGE;     // [X6_RB][4 ex][3 terms][X6N][X6K]
+  unsigned short* Bs = smem6 + X6_RA * F::A_STAGE;     // [X6_RB][4 ex][3 terms][X6N][X6K]
   const int tid = threadIdx.x, lane = tid & 63, hw_wid = tid >> 6;
 #ifdef X6_INTERLEAVE_ROLES
   const bool producer = hw_wid & 1;
@@ -232,7 +287,8 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = p_sub4(dA[d][j], dB[d][j]);
       }
-      x6_store(e, la + slot * X6_A_STAGE);
+      if (FMT) h3_store(e, la + slot * F::A_STAGE, sa);
+      else x6_store(e, la + slot * F::A_STAGE);
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) issue(d);
@@ -271,10 +327,11 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   }
   // B loader (LDS-DMA): 24 one-KB instructions per stage = (ex, term) image pt x 32-row half; wave w issues q = 6w .. 6w+5.
   // Lane l of an instruction covers row (q & 1) * 32 + (l >> 1), 16-byte half (l & 1) of the 32-byte row.
-  unsigned b_voff[6];
+  constexpr int QW = F::DMA_PER_WAVE;                 // 6 (bf16) / 4 (fp16) one-KB instructions per wave and stage
+  unsigned b_voff[QW];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int q = wid * 6 + i, pt = q >> 1;
+  for (int i = 0; i < QW; ++i) {
+    const int q = wid * QW + i, pt = q >> 1;
     const int row = (q & 1) * 32 + (lane >> 1);
     const int n = n0 + row;
     const int half = (lane ^ (row >> 3)) & 1;           // logical half stored at physical half (lane & 1)
@@ -283,11 +340,11 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   X6Seq lb; lb.init(chunks, p.up);
   int ld_slot = 0;
   auto issue_b = [&]() {                              // weights of the next stage of the sequence -> next ring slot
-    const int kb = ((lb.ey * (p.Cin >> 4) + c_begin + lb.chunk()) * 12 * p.wrows) << 5;   // (ey, chunk) block of twelve [ex][term] images of wrows x 32 bytes
-    unsigned short* dst = Bs + ld_slot * X6_B_STAGE + (wid * 6) * 512;           // 512 elements = one KB per instruction
+    const int kb = ((lb.ey * (p.Cin >> 4) + c_begin + lb.chunk()) * (4 * TERMS) * p.wrows) << 5;   // (ey, chunk) block of twelve [ex][term] images of wrows x 32 bytes
+    unsigned short* dst = Bs + ld_slot * F::B_STAGE + (wid * QW) * 512;           // 512 elements = one KB per instruction
     if (!(X6_ABL & 4)) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < QW; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (x6_lds_void*)(dst + i * 512), 16, (int)b_voff[i], kb, 0, 0);
     }
     lb.next(chunks);
@@ -317,30 +374,30 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     if (tl) TL[0] = __builtin_readcyclecounter();
     // B(t) was issued three stages ago; B(t+1) and B(t+2) (six instructions each) may still be in flight.  Plain s_barrier +
     // explicit counters: a release fence would drain the weight prefetch (vmcnt(0)).
-    if (t + 2 < S) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (t + 1 < S) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 2 < S) { if (FMT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    else if (t + 1 < S) { if (FMT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (tl) TL[1] = __builtin_readcyclecounter();
     if (t + 3 < S) issue_b();
-    const unsigned short* Ab = As + (t & 1) * X6_A_STAGE + a_foff;
-    const unsigned short* Bb = Bs + slot_b * X6_B_STAGE + b_foff;
+    const unsigned short* Ab = As + (t & 1) * F::A_STAGE + a_foff;
+    const unsigned short* Bb = Bs + slot_b * F::B_STAGE + b_foff;
     if (++slot_b == X6_RB) slot_b = 0;
     const bool first = cs.cc == 0;                    // first stage of a (block, ey) group: C = 0, no accumulator clearing
     // Fragment reads are issued ONE ex GROUP AHEAD of the MFMAs that use them (two register sets): left to itself the compiler
     // reads a group's six fragments right before its six MFMAs, so every group starts with an exposed LDS round trip (~130 cycles,
     // four times per stage) -- a read returns while the matrix pipe works only if it was issued before the chain it follows
     // (tools/overlap_probe2.hip: ds_read_b128 interleaved with MFMAs of the same wave costs ~6 cycles each, not a latency).
-    bf16x8 fa[2][3], fb[2][3];
+    u32x4 fa[2][TERMS], fb[2][TERMS];            // 8 bf16 / fp16 values per fragment
     auto frag = [&](int xi, int set) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < TERMS; ++k) {
         if (X6_ABL & 16) {
-          fa[set][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, (unsigned)t, 0x3f803f80u, (unsigned)xi});
-          fb[set][k] = __builtin_bit_cast(bf16x8, u32x4{0x3f003f00u, (unsigned)k, 0x3f003f00u, (unsigned)lane});
+          fa[set][k] = u32x4{0x3f803f80u, (unsigned)t, 0x3f803f80u, (unsigned)xi};
+          fb[set][k] = u32x4{0x3f003f00u, (unsigned)k, 0x3f003f00u, (unsigned)lane};
           continue;
         }
-        fa[set][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab + (xi * 3 + k) * X6P_T * X6K));
-        fb[set][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb + (xi * 3 + k) * X6N * X6K));
+        fa[set][k] = *reinterpret_cast<const u32x4*>(Ab + (xi * TERMS + k) * X6P_T * X6K);
+        fb[set][k] = *reinterpret_cast<const u32x4*>(Bb + (xi * TERMS + k) * X6N * X6K);
       }
     };
     auto products = [&](auto first_tag) {
@@ -351,14 +408,24 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
         if (xi < 3) frag(xi + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);            // (keeps the next group's reads above this group's chain)
         if (X6_ABL & 8) continue;
-        const bf16x8 *a = fa[cur], *b = fb[cur];
-        // small products first
-        f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], decltype(first_tag)::value ? zero : acc[xi], 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        const f32x16 c0 = decltype(first_tag)::value ? zero : acc[xi];
+        if (FMT) {                                  // three fp16 products, small ones first
+          const f16x8 a0 = __builtin_bit_cast(f16x8, fa[cur][0]), a1 = __builtin_bit_cast(f16x8, fa[cur][1]);
+          const f16x8 b0 = __builtin_bit_cast(f16x8, fb[cur][0]), b1 = __builtin_bit_cast(f16x8, fb[cur][1]);
+          f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c0, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+        } else {                                    // six bf16 products, small ones first
+          bf16x8 a[3], b[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { a[k] = __builtin_bit_cast(bf16x8, fa[cur][k % TERMS]); b[k] = __builtin_bit_cast(bf16x8, fb[cur][k % TERMS]); }
+          f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c0, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -410,7 +477,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, Y[a][c][r] + bv + rv[a][c]), rs_y, (int)oy[a][c], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (FMT ? Y[a][c][r] * inv_scale : Y[a][c][r]) + bv + rv[a][c]), rs_y, (int)oy[a][c], 0, 0);
     }
     return;
   }
@@ -425,7 +492,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const long px = px0 + (long)a * p.W;
-      float y0 = Y[a][0][r] + bv, y1 = Y[a][1][r] + bv;
+      float y0 = (FMT ? Y[a][0][r] * inv_scale : Y[a][0][r]) + bv, y1 = (FMT ? Y[a][1][r] * inv_scale : Y[a][1][r]) + bv;
       if (p.res) { y0 += p.res[px * p.ldr + n]; y1 += p.res[(px + 1) * p.ldr + n]; }
       p.y[px * p.ldy + n] = y0;
       p.y[(px + 1) * p.ldy + n] = y1;
@@ -457,6 +524,28 @@ __global__ void split3_kernel(const float* __restrict__ src, unsigned short* __r
   }
 }
 
+// fp16 format: dst[ey][cols/16][ex][term(2)][rows][16] <- the two-term round-to-nearest split of scale * src (the sixteen Winograd
+// planes); *overflow is raised when a scaled value leaves the fp16 range (the caller then falls back to the bf16 format)
+__global__ void split2_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int rows, int cols, float scale,
+                              int* __restrict__ overflow) {
+  const long per = (long)rows * cols, total = per * 16;
+  const int chunks = cols >> 4;
+  bool bad = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int img = (int)(i / per);
+    const long rc = i - img * per;
+    const int n = (int)(rc / cols), c = (int)(rc - (long)n * cols);
+    const int ey = img >> 2, ex = img & 3;
+    const float a = src[i] * scale;
+    bad |= !(fabsf(a) < 65000.f);
+    const _Float16 h0 = (_Float16)a, h1 = (_Float16)(a - (float)h0);
+    unsigned short* d = dst + ((((long)(ey * chunks + (c >> 4)) * 8 + ex * 2) * rows + n) << 4) + (c & 15);
+    d[0] = __builtin_bit_cast(unsigned short, h0);
+    d[(long)rows << 4] = __builtin_bit_cast(unsigned short, h1);
+  }
+  if (bad && overflow) *overflow = 1;
+}
+
 }  // namespace
 
 int adm_splitk_reduce(const float* ws, const float* bias, const float* res, float* y, long M, int N, int ldy, int ldr, int splitk,
@@ -473,20 +562,34 @@ extern "C" int adm_split3_bf16(const float* src, void* dst, int rows, int cols, 
   return ADM_OK;
 }
 
+// fp16 format of the weight operand (see X6Fmt<1>): dst = 32 * rows * cols fp16 values, layout [ey][cols/16][ex][term(2)][rows][16]
+extern "C" int adm_split2_f16(const float* src, void* dst, int rows, int cols, float scale, int* overflow, hipStream_t stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 15) || !(scale > 0.f)) return ADM_EINVAL;
+  const long total = (long)rows * cols * 16;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(split2_kernel, dim3(grid), dim3(256), 0, stream, src, static_cast<unsigned short*>(dst), rows, cols, scale, overflow);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
 // Same contract as adm_conv_fwd_wino2d, with wq6 = adm_split3_bf16 of the adm_pack_weight_wino2d operand (16 planes of
 // wrows x Cin).
 static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws, long ws_floats,
-                            int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int up, hipStream_t stream) {
+                            int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int up, hipStream_t stream,
+                            const float* amax_x = nullptr, float wscale = 0.f) {
+  const bool h3 = amax_x != nullptr;                   // fp16 format: wq6 is the adm_split2_f16 image (scale wscale), amax_x >= max |x| on the device
   if (!x || !wq6 || !y || B <= 0 || H < 2 || W < 2 || (W & 1) || (H & 1)) return ADM_EINVAL;
   if ((Cin & 31) || (ldx & 3) || N <= 0 || wrows < N) return ADM_EINVAL;      // an even number of 16-channel chunks
   if (((uintptr_t)x | (uintptr_t)wq6) & 15) return ADM_EINVAL;
   X6P p;
   p.x = x; p.w = static_cast<const unsigned short*>(wq6); p.bias = bias; p.res = res; p.y = y;
   const long Mt = (long)B * (H / 2) * (W / 2);
-  const long xb = (long)B * H * W * ldx * 4 / (up ? 4 : 1), wb = 48L * wrows * Cin * 2;
+  const long xb = (long)B * H * W * ldx * 4 / (up ? 4 : 1), wb = (h3 ? 32L : 48L) * wrows * Cin * 2;
+  if (h3 && !(wscale > 0.f)) return ADM_EINVAL;
   if (Mt >= (1L << 30) || xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;
   p.Mt = (int)Mt; p.N = N; p.H = H; p.W = W; p.Hh = H / 2; p.Wh = W / 2; p.Cin = Cin; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin; p.up = up ? 1 : 0;
+  p.amax_x = amax_x; p.wscale = wscale;
   p.tilesN = adm_cdiv(N, X6N);
   p.splitk = 1; p.chunks_per_split = 0; p.ws = X6_TL ? ws : nullptr;
   const long yb = (long)B * H * W * ldy * 4, rb = res ? (long)B * H * W * ldr * 4 : 0;
@@ -499,19 +602,30 @@ static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, 
     p.splitk = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     p.ws = ws;
   }
-  constexpr int smem = (X6_RA * X6_A_STAGE + X6_RB * X6_B_STAGE) * (int)sizeof(unsigned short);
+  constexpr int smem0 = (X6_RA * X6Fmt<0>::A_STAGE + X6_RB * X6Fmt<0>::B_STAGE) * (int)sizeof(unsigned short);
+  constexpr int smem1 = (X6_RA * X6Fmt<1>::A_STAGE + X6_RB * X6Fmt<1>::B_STAGE) * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
   const long grid = (long)adm_cdiv(Mt, X6P_T) * p.tilesN;
-  hipLaunchKernelGGL(wino2d_x6_kernel, dim3((unsigned)grid, p.splitk), dim3(512), smem, stream, p);
+  if (h3) hipLaunchKernelGGL(wino2d_x6_kernel<1>, dim3((unsigned)grid, p.splitk), dim3(512), smem1, stream, p);
+  else hipLaunchKernelGGL(wino2d_x6_kernel<0>, dim3((unsigned)grid, p.splitk), dim3(512), smem0, stream, p);
   ADM_CHECK_LAUNCH();
   if (p.splitk > 1) return adm_splitk_reduce(ws, bias, res, y, Mt * 4, N, ldy, ldr, p.splitk, stream);
   return ADM_OK;
+}
+
+// fp16 format (three fp16 products per f32 product): wqh = adm_split2_f16(planes, scale = wscale), amax_x = device scalar >= max |x|
+// (an upper bound; too large only costs precision on the smallest values); up != 0: the fused nearest x2 form
+extern "C" int adm_conv_fwd_wino2d_h3(const float* x, const void* wqh, const float* bias, const float* res, float* y, float* ws,
+                                      long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                                      const float* amax_x, float wscale, int up, hipStream_t stream) {
+  if (!amax_x) return ADM_EINVAL;
+  return wino2d_x6_launch(x, wqh, bias, res, y, ws, ws_floats, B, H, W, Cin, ldx, N, wrows, ldy, ldr, up, stream, amax_x, wscale);
 }
 
 extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,

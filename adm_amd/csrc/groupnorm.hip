@@ -24,6 +24,18 @@ __device__ __forceinline__ void gn_store4(float* y, long quad_idx, f32x4 u, int 
   }
 }
 
+// max |y| of a GroupNorm output for the fp16-format conv that consumes it (conv_wino2d_x6.hip, X6Fmt<1>): per-thread maximum ->
+// wave maximum -> one atomicMax per wave on the float's bit pattern (non-negative floats order like unsigned integers)
+__device__ __forceinline__ float gn_amax4(float am, f32x4 u) {
+  return fmaxf(fmaxf(am, fmaxf(fabsf(u[0]), fabsf(u[1]))), fmaxf(fabsf(u[2]), fabsf(u[3])));
+}
+__device__ __forceinline__ void gn_amax_commit(float am, float* amax) {
+  if (!amax) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+  if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(am));
+}
+
 __host__ __device__ inline int gn_rows_par(int C) { int r = 256 / (C / 4); return r < 1 ? 1 : r; }
 
 // ---------------------------------------------------------------- forward: moments
@@ -111,11 +123,12 @@ __global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restr
 __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ ss, long ss_bstride, float* __restrict__ y, int HW, int C,
-                                int G, int rows_per_split, int silu, float drop_p, uint64_t seed, int out_bf16) {
+                                int G, int rows_per_split, int silu, float drop_p, uint64_t seed, int out_bf16, float* __restrict__ amax) {
   const int C4 = C >> 2, R = blockDim.x / C4;
   const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
   const int b = blockIdx.x;
   const int hw0 = blockIdx.y * rows_per_split, hw1 = min(HW, hw0 + rows_per_split);
+  float am = 0.f;
   const int cpg = C / G;
   f32x4 ca, cb;
 #pragma unroll
@@ -140,8 +153,10 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
       for (int k = 0; k < 4; ++k) u[k] = silu_f(u[k]);
     }
     if (drop_p > 0.f) u *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + cq, drop_p, inv_keep);
+    am = gn_amax4(am, u);
     gn_store4(y, ybase + (long)hw * C4 + cq, u, out_bf16);
   }
+  gn_amax_commit(am, amax);
 }
 
 // ---------------------------------------------------------------- backward pass 1: per (b, split, c) partials
@@ -352,7 +367,8 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 3)) void gn_fused_fwd_ker
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
                                                            long ss_bstride, float* __restrict__ y,
                                                            float* __restrict__ stats, int HW, int C, int G, int Cc,
-                                                           float eps, int silu, float drop_p, uint64_t seed, int out_bf16) {
+                                                           float eps, int silu, float drop_p, uint64_t seed, int out_bf16,
+                                                           float* __restrict__ amax) {
   extern __shared__ float sm[];                    // [R][Cc][2] partials | [Gc][2] mean, rstd
   const int Cc4 = Cc >> 2, R = blockDim.x / Cc4, C4 = C >> 2;
   const int cq = threadIdx.x % Cc4, ry = threadIdx.x / Cc4;
@@ -434,6 +450,7 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 3)) void gn_fused_fwd_ker
   }
   const long ybase = (long)b * HW * C4 + (c0 >> 2);  // in channel quads
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
     const int hw = ry + i * R;
@@ -444,9 +461,11 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 3)) void gn_fused_fwd_ker
       for (int k = 0; k < 4; ++k) u[k] = silu_f(u[k]);
     }
     if (drop_p > 0.f) u *= dropout_keep4(seed, ((uint64_t)b * HW + hw) * C4 + (c0 >> 2) + cq, drop_p, inv_keep);
+    am = gn_amax4(am, u);
     gn_store4(y, ybase + (long)hw * C4 + cq, u, out_bf16);
     __builtin_amdgcn_sched_barrier(0);            // one row at a time: interleaving the rows' hashes / exponentials costs registers
   }
+  gn_amax_commit(am, amax);
 }
 
 // (second launch bound = waves per SIMD: left alone the compiler hoists the dropout hashes and SiLU derivatives of all rows and
@@ -618,12 +637,12 @@ extern "C" int adm_gn_stats(const float* x, float* stats, double* ws, int B, int
 
 static int gn_apply_impl(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss, long ss_bstride,
                          float* y, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, int out_bf16,
-                         hipStream_t stream) {
+                         hipStream_t stream, float* amax = nullptr) {
   if (!x || !stats || !gamma || !beta || !y || !gn_shape_ok(B, HW, C, G) || drop_p < 0.f || drop_p >= 1.f)
     return ADM_EINVAL;
   int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(B, S), dim3(gn_threads(C)), 0, stream, x, stats, gamma, beta, ss,
-                     ss_bstride, y, HW, C, G, rows, silu, drop_p, seed, out_bf16);
+                     ss_bstride, y, HW, C, G, rows, silu, drop_p, seed, out_bf16, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -636,7 +655,15 @@ extern "C" int adm_gn_apply(const float* x, const float* stats, const float* gam
 
 static int gn_fwd_impl(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
                        long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
-                       int out_bf16, hipStream_t stream);
+                       int out_bf16, hipStream_t stream, float* amax = nullptr);
+
+// adm_gn_fwd that also raises *amax (a device float the caller zeroed) to max |y|: the scale basis of the fp16-format conv that
+// consumes y (adm_conv_fwd_wino2d_h3)
+extern "C" int adm_gn_fwd_amax(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+                               long ss_bstride, float* y, float* amax, int B, int HW, int C, int G, float eps, int silu, float drop_p,
+                               uint64_t seed, hipStream_t stream) {
+  return gn_fwd_impl(x, stats, ws, gamma, beta, ss, ss_bstride, y, B, HW, C, G, eps, silu, drop_p, seed, 0, stream, amax);
+}
 
 extern "C" int adm_gn_fwd(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
                           long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p,
@@ -655,21 +682,21 @@ extern "C" int adm_gn_fwd_bf16out(const float* x, float* stats, double* ws, cons
 
 static int gn_fwd_impl(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
                        long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
-                       int out_bf16, hipStream_t stream) {
+                       int out_bf16, hipStream_t stream, float* amax) {
   if (!x || !stats || !ws || !gamma || !beta || !y || !gn_shape_ok(B, HW, C, G) || drop_p < 0.f || drop_p >= 1.f)
     return ADM_EINVAL;
   const GnPlan pl = g_gn_fused ? gn_fused_plan(HW, C, G, false) : GnPlan{0, 0, 0};
   if (pl.Cc == 0) {
     int rc = adm_gn_stats(x, stats, ws, B, HW, C, G, eps, stream);
     if (rc != ADM_OK) return rc;
-    return gn_apply_impl(x, stats, gamma, beta, ss, ss_bstride, y, B, HW, C, G, silu, drop_p, seed, out_bf16, stream);
+    return gn_apply_impl(x, stats, gamma, beta, ss, ss_bstride, y, B, HW, C, G, silu, drop_p, seed, out_bf16, stream, amax);
   }
   const int Cc = pl.Cc, R = pl.threads / (Cc / 4), Gc = Cc / (C / G);
   const size_t smem = ((size_t)R * Cc * 2 + (size_t)((Gc * 2 + 1) & ~1)) * sizeof(float) + (size_t)Cc * sizeof(double);
   const dim3 grid(C / Cc, B), block(pl.threads);
 #define GN_FWD(MAXR, THREADS)                                                                                                 \
   hipLaunchKernelGGL((gn_fused_fwd_kernel<MAXR, THREADS>), grid, block, smem, stream, x, gamma, beta, ss, ss_bstride, y, stats, \
-                     HW, C, G, Cc, eps, silu, drop_p, seed, out_bf16)
+                     HW, C, G, Cc, eps, silu, drop_p, seed, out_bf16, amax)
   if (pl.rows <= 2) GN_FWD(2, 256);
   else if (pl.rows <= 8) GN_FWD(8, 256);
   else GN_FWD(14, 256);

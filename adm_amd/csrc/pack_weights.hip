@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 // (out-channel) x 32 (in-channel) tile of one layer: the tile's taps-interleaved source runs (32*taps contiguous floats per
 // out-channel) go through LDS once and leave as 128-byte row segments of every operand layout, so reads and writes are
 // coalesced (the previous element-per-thread gather ran at 0.7 TB/s and cost 3.8 ms per optimiser step).
-constexpr int PT_COLS = 18;
+constexpr int PT_COLS = 22;      // 18, 19: fp16-format images of the 2-D Winograd operands; 20: their scale (float bits); 21: overflow flag (int*)
 __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict__ table, int n_entries) {
   __shared__ float tile[32][32 * 9 + 1];
   // layer of this tile: last row whose tile_begin <= blockIdx.x
@@ -191,14 +191,21 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
   float* __restrict__ wb2 = reinterpret_cast<float*>(t[13]);
   unsigned short* __restrict__ wf6 = reinterpret_cast<unsigned short*>(t[14]);
   unsigned short* __restrict__ wb6 = reinterpret_cast<unsigned short*>(t[15]);
-  if (wf2 || wb2 || wf6 || wb6) {
+  // ... and their two-term fp16 images [ey][cols/16][ex][term(2)][rows][16] of scale * U (conv_wino2d_x6.hip, X6Fmt<1>)
+  unsigned short* __restrict__ wfh = reinterpret_cast<unsigned short*>(t[18]);
+  unsigned short* __restrict__ wbh = reinterpret_cast<unsigned short*>(t[19]);
+  const float hscale = __uint_as_float((unsigned)t[20]);
+  int* __restrict__ hflag = reinterpret_cast<int*>(t[21]);
+  bool hbad = false;
+  if (wf2 || wb2 || wf6 || wb6 || wfh || wbh) {
     const long plane2 = (long)Co_pad * Ci_pad;
     for (int e = threadIdx.x; e < 32 * 32; e += 256) {
       // forward operand: ci fastest; data-gradient operand: co fastest -> two index maps over the same 32 x 32 tile
       for (int which = 0; which < 2; ++which) {
         float* __restrict__ dst = which ? wb2 : wf2;
         unsigned short* __restrict__ dst6 = which ? wb6 : wf6;
-        if (!dst && !dst6) continue;
+        unsigned short* __restrict__ dsth = which ? wbh : wfh;
+        if (!dst && !dst6 && !dsth) continue;
         const int fast = e & 31, slow = e >> 5;
         const int co_l = which ? fast : slow, ci_l = which ? slow : fast;
         const float* g = &tile[co_l][ci_l * 9];
@@ -231,10 +238,21 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
               d6[term6] = (unsigned short)(b1 >> 16);
               d6[2 * term6] = (unsigned short)(__float_as_uint(r2) >> 16);
             }
+            if (dsth) {                            // scale * u = h0 + h1, round to nearest (as adm_split2_f16)
+              const float a = u[ey] * hscale;
+              hbad |= !(fabsf(a) < 65000.f);
+              const _Float16 h0 = (_Float16)a, h1 = (_Float16)(a - (float)h0);
+              const int rowsh = which ? Ci_pad : Co_pad, colsh = which ? Co_pad : Ci_pad;
+              const int nh = which ? ci0 + ci_l : co0 + co_l, ch = which ? co0 + co_l : ci0 + ci_l;
+              unsigned short* dh = dsth + ((((long)(ey * (colsh >> 4) + (ch >> 4)) * 8 + ex * 2) * rowsh + nh) << 4) + (ch & 15);
+              dh[0] = __builtin_bit_cast(unsigned short, h0);
+              dh[(long)rowsh << 4] = __builtin_bit_cast(unsigned short, h1);
+            }
           }
         }
       }
     }
+    if (hbad && hflag) *hflag = 1;                 // a scaled weight left the fp16 range: the host falls back to the bf16 format
   }
   if (wb) {                                        // wb[xi][ci][ky'][co]: co fastest; g'(ky', kx') = w(2-ky', 2-kx')
     const long plane = (long)Ci_pad * 3 * Co_pad;

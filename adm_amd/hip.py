@@ -34,6 +34,8 @@ _SIGS = {
     "adm_conv_fwd_wino2d_x6_up": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P],
     "adm_wino2d_x6_splitk": [I, I, I, I, I],
     "adm_split3_bf16": [P, P, I, I, P],
+    "adm_split2_f16": [P, P, I, I, F, P, P],
+    "adm_conv_fwd_wino2d_h3": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P, F, I, P],
     "adm_gemm_x6": [P, P, P, P, P, L, I, I, I, I, I, I, P],
     "adm_split3_rows": [P, P, I, I, I, P],
     "adm_conv_wgrad_x6": [P, P, P, P, I, I, I, I, I, I, I, I, P],
@@ -72,6 +74,7 @@ _SIGS = {
     "adm_gn_stats": [P, P, P, I, I, I, I, F, P],
     "adm_gn_apply": [P, P, P, P, P, L, P, I, I, I, I, I, F, U, P],
     "adm_gn_fwd": [P, P, P, P, P, P, L, P, I, I, I, I, F, I, F, U, P],
+    "adm_gn_fwd_amax": [P, P, P, P, P, P, L, P, P, I, I, I, I, F, I, F, U, P],
     "adm_gn_bwd": [P, P, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, F, U, P],
     "adm_gn_bwd_add": [P, P, P, P, P, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P],
     "adm_softmax_rows": [P, L, I, L, F, P],

@@ -61,7 +61,7 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 # packed-weight cache
 # ------------------------------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "w2f6", "w2b6", "g6f", "g6b", "src")
+    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "w2f6", "w2b6", "w2fh", "w2bh", "g6f", "g6b", "src")
 
 
 # Contraction precision of the conv / Linear kernels: "f32" (default: exact fp32 MFMA) or "bf16" (BASELINE
@@ -83,6 +83,53 @@ WINOGRAD2D = os.environ.get("ADM_WINOGRAD2D", "1") != "0"
 # six bf16 MFMAs per product block, f32 accumulation; error against fp64 at or below the f32 MFMA kernel's, see
 # tests/test_hip_ops.py::test_conv_x6_error_vs_fp64).  ADM_BF16X6=0 keeps the f32-MFMA kernels of conv_wino2d.hip.
 BF16X6 = os.environ.get("ADM_BF16X6", "1") != "0"
+# ... or, where the activation operand comes with an upper bound of its magnitude (a GroupNorm output: the GroupNorm kernel writes
+# max |y| next to it), on THREE fp16 MFMAs per product: two-term round-to-nearest split after a power-of-two scaling (conv_wino2d_x6.hip,
+# X6Fmt<1>).  Same error against fp64 as the six-bf16 form (tools/fp16x3_accuracy.py, tests/test_hip_ops.py::test_conv_h3_*), half its
+# matrix, LDS and split work.  Weights use one fixed power-of-two scale: a scaled weight leaving the fp16 range raises a device flag
+# that repack_all() reads every 64 steps and that switches the format off (never observed: it takes a Winograd-domain weight >= 32).
+# ADM_FP16X3=0 keeps every split kernel on the bf16 format.
+FP16X3 = os.environ.get("ADM_FP16X3", "1") != "0"
+H3_WSCALE = 2048.0
+_h3_flag = None             # device int32: raised by the weight split kernels on overflow
+_h3_checks = 0
+_amax_pool, _amax_next = None, 0
+_AMAX_POOL = 4096
+
+
+def _amax_slot(like: torch.Tensor) -> torch.Tensor:
+    """A zeroed device float for a kernel to raise to max |output| (atomicMax).  Slots come from a pool that is zero-filled once per
+    4096 slots (no per-call fill launch); a slot lives as long as a tensor refers to it."""
+    global _amax_pool, _amax_next
+    if _amax_pool is None or _amax_next >= _AMAX_POOL or _amax_pool.device != like.device:
+        _amax_pool, _amax_next = torch.zeros(_AMAX_POOL, device=like.device, dtype=_f32), 0
+    s = _amax_pool[_amax_next:_amax_next + 1]
+    _amax_next += 1
+    return s
+
+
+def _h3_flag_tensor(like):
+    global _h3_flag
+    if _h3_flag is None or _h3_flag.device != like.device:
+        _h3_flag = torch.zeros(1, device=like.device, dtype=torch.int32)
+    return _h3_flag
+
+
+def _h3_operands(weight: torch.Tensor, ent: "_Packed"):
+    """fp16-format images of the 2-D Winograd operands (forward image built on first use from the f32 planes; afterwards refreshed
+    by repack_all() with the rest).  Returns the forward image."""
+    global _pack_table
+    if ent.w2fh is None:
+        co, ci = weight.shape[0], weight.shape[1]
+        cop, cip = ceil32(co), ceil32(ci)
+        w = _chk(weight.detach(), "weight")
+        w2f, w2b = _new((16, cop, cip), w), _new((16, cip, cop), w)
+        call("adm_pack_weight_wino2d", ptr(w), ptr(w2f), ptr(w2b), co, ci, cop, cip)
+        ent.w2fh = torch.empty((16, 2, cop, cip), device=w.device, dtype=torch.float16)
+        call("adm_split2_f16", ptr(w2f), ptr(ent.w2fh), cop, cip, H3_WSCALE, ptr(_h3_flag_tensor(w)))
+        _pack_table = None           # the one-launch repack table must learn the new destination
+    return ent.w2fh
+
 
 # ADM_DETERMINISTIC=1: bitwise reproducible backward.  The weight / bias gradient kernels normally combine their pixel-range
 # splits with fp32 atomics (order-dependent rounding); with this switch every split stores its partial tile to a workspace
@@ -244,6 +291,7 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     ent.wf = ent.wb = None
     ent.w2f = ent.w2b = None
     ent.w2f6 = ent.w2b6 = None
+    ent.w2fh = ent.w2bh = None
     ent.g6f = ent.g6b = None
     ent.src = (co, ci, ks, qkv)
     ent.fwd = _new((cop, ks * ks * cip), w)
@@ -280,11 +328,20 @@ _pack_registry: dict = {}
 _pack_table = None          # (device int64 table, [entries], total 32x32 tiles, host rows)
 
 
+_H3_WSCALE_BITS = int.from_bytes(__import__("struct").pack("<f", H3_WSCALE), "little")
+
+
 def repack_all():
     """Called by the fused optimiser after it rewrote the flat parameter buffer: re-derives every registered packed
     operand in place with one kernel launch and marks the entries current."""
-    global _pack_table, _pack_epoch
+    global _pack_table, _pack_epoch, _h3_checks, FP16X3
     _pack_epoch += 1
+    if _h3_flag is not None and FP16X3:
+        _h3_checks += 1
+        if _h3_checks % 64 == 0 and int(_h3_flag) != 0:      # (one 4-byte read-back per 64 optimiser steps)
+            FP16X3 = False
+            print("adm_amd: a Winograd-domain weight left the fp16 range at scale 2^11: the split kernels continue on the bf16 format",
+                  flush=True)
     if _pack_table is None:
         rows, ents, tiles = [], [], 0
         for key, (wref, bref, ks, qkv) in list(_pack_registry.items()):
@@ -299,7 +356,9 @@ def repack_all():
                          0 if ent.wf is None else ent.wf.data_ptr(), 0 if ent.wb is None else ent.wb.data_ptr(),
                          0 if ent.w2f is None else ent.w2f.data_ptr(), 0 if ent.w2b is None else ent.w2b.data_ptr(),
                          0 if ent.w2f6 is None else ent.w2f6.data_ptr(), 0 if ent.w2b6 is None else ent.w2b6.data_ptr(),
-                         0 if ent.g6f is None else ent.g6f.data_ptr(), 0 if ent.g6b is None else ent.g6b.data_ptr()])
+                         0 if ent.g6f is None else ent.g6f.data_ptr(), 0 if ent.g6b is None else ent.g6b.data_ptr(),
+                         0 if ent.w2fh is None else ent.w2fh.data_ptr(), 0 if ent.w2bh is None else ent.w2bh.data_ptr(),
+                         _H3_WSCALE_BITS, 0 if ent.w2fh is None and ent.w2bh is None else _h3_flag_tensor(w).data_ptr()])
             tiles += (cop // 32) * (cip // 32)         # column 9 = exclusive prefix sum of 32x32 tiles
             ents.append((wref, bref, ks, qkv, ent))
         if not rows:
@@ -677,7 +736,7 @@ def _conv_f32(x, wp, bias, res, y, B, Ho, Wo, cin_p, n_p, ks, up, tile, wq=None,
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, ks, up, qkv, tile):
+    def forward(ctx, x, weight, bias, residual, ks, up, qkv, tile, amax=None):
         x = _chk(x, "x")
         B, H, W, cx = x.shape
         co, ci = weight.shape[0], weight.shape[1]
@@ -701,10 +760,16 @@ class _Conv(torch.autograd.Function):
         wq2 = _wino2_operands(weight, pk)[0] if (wino and _use_wino2d(B, Ho, Wo, ks, up, tile)) else None
         wq = _wino_operands(weight, pk)[0] if (wino and wq2 is None) else None
         g6 = not use_bf16 and _use_gemm_x6(_sel_batch(B) * Ho * Wo, ks, up, cop, cip)
-        kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
+        h3 = wq2 is not None and BF16X6 and FP16X3 and amax is not None       # fp16 format: the operand came with its max |x|
+        kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
         with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                    f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
-            if g6:
+            if h3:
+                sk = 1 if _SELECT_BATCH is not None else hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cip, cop)
+                wsk = _new((sk * B * Ho * Wo * cop,), x) if sk > 1 else None
+                call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk)), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
+                     0 if wsk is None else wsk.numel(), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up))
+            elif g6:
                 call("adm_gemm_x6", ptr(x), ptr(_gemm_x6_operands(pk)[0]), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
                      cop, cop, cop)
             elif use_bf16:
@@ -896,12 +961,15 @@ class _Conv(torch.autograd.Function):
                 dx = dxf
         if side is None:
             weight_and_bias_grads()
-        return dx, dw, db, (dy if has_res else None), None, None, None, None
+        return dx, dw, db, (dy if has_res else None), None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, residual=None, *, up=False, qkv=False, tile=-1):
-    """NHWC conv: weight OIHW with k in {1,3}; optional fused nearest-x2 (``up``) and residual add."""
-    return _Conv.apply(x, weight, bias, residual, weight.shape[-1] if weight.dim() == 4 else 1, bool(up), bool(qkv), tile)
+def conv2d(x, weight, bias=None, residual=None, *, up=False, qkv=False, tile=-1, amax=None):
+    """NHWC conv: weight OIHW with k in {1,3}; optional fused nearest-x2 (``up``) and residual add.  amax: a device float >= max |x|
+    (default: the one a GroupNorm kernel attached to x) -- lets the 3x3 layers run on the fp16 split format."""
+    if amax is None:
+        amax = getattr(x, "_adm_amax", None)
+    return _Conv.apply(x, weight, bias, residual, weight.shape[-1] if weight.dim() == 4 else 1, bool(up), bool(qkv), tile, amax)
 
 
 def linear(x, weight, bias=None, residual=None):
@@ -924,7 +992,8 @@ def next_dropout_seed() -> int:
 
 class _GroupNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed, groups=0, eps=1e-5, fork=False, out_bf16=False, slot=None, slot_flag=None):
+    def forward(ctx, x, gamma, beta, ss, silu, drop_p, seed, groups=0, eps=1e-5, fork=False, out_bf16=False, slot=None, slot_flag=None,
+                want_amax=False):
         x_in = x
         x = _chk(x, "x")
         B, H, W, C = x.shape
@@ -954,8 +1023,14 @@ class _GroupNormAct(torch.autograd.Function):
             call("adm_gn_fwd_bf16out", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y16), B, HW, C, G, float(eps),
                  int(silu), float(drop_p), seed)
         else:
-            call("adm_gn_fwd", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), B, HW, C, G, float(eps),
-                 int(silu), float(drop_p), seed)
+            if want_amax:     # the conv that consumes y runs on the fp16 format: it needs max |y| (written next to y by the same kernel)
+                global _gn_amax_out
+                _gn_amax_out = slot_a = _amax_slot(x)
+                call("adm_gn_fwd_amax", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), ptr(slot_a), B, HW, C, G,
+                     float(eps), int(silu), float(drop_p), seed)
+            else:
+                call("adm_gn_fwd", ptr(x), ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(ssc), bstride, ptr(y), B, HW, C, G, float(eps),
+                     int(silu), float(drop_p), seed)
         prof.__exit__()
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (G, S, bstride, silu, drop_p, seed)
@@ -970,7 +1045,7 @@ class _GroupNormAct(torch.autograd.Function):
         x, gamma, beta, ss, stats = ctx.saved_tensors
         G, S, bstride, silu, drop_p, seed = ctx.meta
         if dy is None:    # only the pass-through output was used
-            return dxr, None, None, None, None, None, None, None, None, None, None, None, None
+            return dxr, None, None, None, None, None, None, None, None, None, None, None, None, None
         dy = _chk(dy, "dy")
         add = None if dxr is None else _chk(dxr, "residual gradient")
         B, H, W, C = x.shape
@@ -1007,11 +1082,24 @@ class _GroupNormAct(torch.autograd.Function):
             dss = None                   # (the group's backward node reads the buffer; autograd carries nothing for this edge)
         if direct:
             _notify(gamma); _notify(beta)
-            return dx, None, None, dss, None, None, None, None, None, None, None, None, None
-        return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None, None, None
+            return dx, None, None, dss, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None, None, None, None
 
 
 _gn_bf16_out = None      # the bf16 values of the last bf16-storage GroupNorm forward (picked up by the wrapper below)
+_gn_amax_out = None      # the max |y| slot of the last GroupNorm forward that was asked for one
+
+
+def _attach_amax(y):
+    """Hands max |y| (a device float the GroupNorm kernel wrote) to the consumer: conv2d looks for `_adm_amax` on its input."""
+    global _gn_amax_out
+    if _gn_amax_out is not None:
+        y._adm_amax, _gn_amax_out = _gn_amax_out, None
+    return y
+
+
+def _want_amax(to_conv, x):
+    return bool(to_conv) and FP16X3 and BF16X6 and COMPUTE == "f32" and x.is_cuda
 
 
 def _attach_bf16(y):
@@ -1028,9 +1116,10 @@ def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, s
     mode the values are then written as bf16 and the returned f32 tensor is an unwritten carrier (see _GroupNormAct.forward)."""
     out16 = bool(to_conv) and bf16_storage()
     slot = getattr(scale_shift, "_adm_dss", None) if scale_shift is not None else None       # (set by affine_group())
+    wa = _want_amax(to_conv, x)
     y = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), False, out16,
-                            None if slot is None else slot[0], None if slot is None else slot[1])
-    return _attach_bf16(y) if out16 else y
+                            None if slot is None else slot[0], None if slot is None else slot[1], wa)
+    return _attach_bf16(y) if out16 else (_attach_amax(y) if wa else y)
 
 
 def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5, to_conv=False):
@@ -1040,8 +1129,10 @@ def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0
     if not (torch.is_grad_enabled() and x.requires_grad):
         return group_norm_act(x, gamma, beta, scale_shift, silu=silu, drop_p=drop_p, seed=seed, groups=groups, eps=eps, to_conv=to_conv), x
     out16 = bool(to_conv) and bf16_storage()
-    y, xo = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), True, out16)
-    return (_attach_bf16(y) if out16 else y), xo
+    wa = _want_amax(to_conv, x)
+    y, xo = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), True, out16,
+                                None, None, wa)
+    return (_attach_bf16(y) if out16 else (_attach_amax(y) if wa else y)), xo
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1289,7 +1380,11 @@ class _Resample(torch.autograd.Function):
 
 
 def downsample2x(x):
-    return _Resample.apply(x, 0)
+    y = _Resample.apply(x, 0)
+    a = getattr(x, "_adm_amax", None)
+    if a is not None:
+        y._adm_amax = a              # a 2x2 mean is bounded by the bound of its inputs
+    return y
 
 
 def upsample2x(x):

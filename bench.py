@@ -299,7 +299,7 @@ def main():
         # Winograd kernels execute 2/3 of the direct convolution's 2*M*N*9*Cin -- so frac = achieved / peak is a true roofline
         # fraction (<= 1) and is comparable with the PMC MFMA-busy fraction; the ALGORITHMIC (direct-convolution) rate, which
         # is what images/s follow, is carried beside it as `algorithmic` / `algorithmic_over_peak` (may exceed 1).
-        dom_kind = max((k for k in ("wino2x6", "wino2", "wino", "igemm") if k in by), key=lambda k: by[k][1])
+        dom_kind = max((k for k in ("wino2x6", "wino2h3", "wino2", "wino", "igemm") if k in by), key=lambda k: by[k][1])
         # HBM-side traffic per launch comes from rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
         # WRITE_SIZE runs, FETCH doubled per MI355X_MICROARCH.md): counters cannot be read from inside the process.
         traffic_src, pmc_all = None, {}
@@ -314,10 +314,12 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         # wino2x6: f32 products carried by SIX bf16 MFMAs (exact three-term split): its MFMA pipe executes 6 x 4/9 of the algorithmic
         # flops as bf16 flops and is priced against the bf16 peak
-        PEAKS = {"wino2x6": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2x6": PEAK_BF16_MFMA_TFLOPS, "gemmx6": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmx6": PEAK_BF16_MFMA_TFLOPS}
-        PMC_CLASS = {"wino2x6": "wino2d_x6", "wino2": "wino2d", "wgrad_wino2": "wgrad_wino2d", "wgrad_wino2x6": "wgrad_x6", "gemmx6": "gemm_x6", "wgrad_gemmx6": "wgrad_x6", "attn": "attn"}
-        EXEC = {"wino2x6": 6.0 * 4.0 / 9.0, "wgrad_wino2x6": 6.0 * 4.0 / 9.0, "gemmx6": 6.0, "wgrad_gemmx6": 6.0, "wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino2": 4.0 / 9.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
-        NAMES = {"wino2x6": "wino2d_x6_kernel (3x3 conv forward + data-gradient, 2-D Winograd F(2x2,3x3); f32 products as six bf16 MFMAs "
+        PEAKS = {"wino2h3": PEAK_BF16_MFMA_TFLOPS, "wino2x6": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2x6": PEAK_BF16_MFMA_TFLOPS, "gemmx6": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmx6": PEAK_BF16_MFMA_TFLOPS}
+        PMC_CLASS = {"wino2h3": "wino2d_x6", "wino2x6": "wino2d_x6", "wino2": "wino2d", "wgrad_wino2": "wgrad_wino2d", "wgrad_wino2x6": "wgrad_x6", "gemmx6": "gemm_x6", "wgrad_gemmx6": "wgrad_x6", "attn": "attn"}
+        EXEC = {"wino2h3": 3.0 * 4.0 / 9.0, "wino2x6": 6.0 * 4.0 / 9.0, "wgrad_wino2x6": 6.0 * 4.0 / 9.0, "gemmx6": 6.0, "wgrad_gemmx6": 6.0, "wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino2": 4.0 / 9.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
+        NAMES = {"wino2h3": "wino2d_x6_kernel<1> (3x3 conv forward, 2-D Winograd F(2x2,3x3); f32 products as THREE fp16 MFMAs on a two-term "
+                            "round-to-nearest fp16 split scaled by the operand's max (written by the GroupNorm kernel), f32 accumulate)",
+                 "wino2x6": "wino2d_x6_kernel<0> (3x3 conv forward + data-gradient, 2-D Winograd F(2x2,3x3); f32 products as six bf16 MFMAs "
                             "on the exact three-term bf16 split, f32 accumulate)",
                  "wino2": "igemm_wino2d_kernel (3x3 conv forward + data-gradient, 2-D Winograd F(2x2,3x3), fp32 MFMA)",
                  "wino": "igemm_wino_kernel (3x3 conv forward + data-gradient, Winograd F(2,3): fused-upsample / odd-height layers)",
@@ -350,6 +352,11 @@ def main():
                 e["f32_equivalent"] = round(fl * 4.0 / 9.0 / ms / 1e9, 2)
             if kind in ("gemmx6", "wgrad_gemmx6"):
                 e["f32_equivalent"] = round(fl / ms / 1e9, 2)
+            if kind == "wino2h3":
+                e["f32_equivalent"] = round(fl * 4.0 / 9.0 / ms / 1e9, 2)
+                e["note"] = ("three fp16 MFMAs per f32 product (two-term round-to-nearest split after a power-of-two scaling by the operand's "
+                             "maximum): `achieved` = executed fp16 MFMA flops / kernel time against the dense 16-bit MFMA peak; error vs fp64 = "
+                             "the six-bf16 form's (tests/test_hip_ops.py::test_conv_h3_error_vs_fp64)")
             if kind == "wino2x6":
                 e["f32_equivalent"] = round(fl * 4.0 / 9.0 / ms / 1e9, 2)
                 e["note"] = ("`achieved` = executed bf16 MFMA flops (six bf16 products per f32 product x 4/9 of the direct convolution's "
@@ -369,7 +376,7 @@ def main():
                      "convention": "achieved = EXECUTED MFMA flops / kernel time (HIP events around every launch of one profiled step); "
                              "frac = achieved / peak.  Winograd executes 4/9 (2-D F(2x2,3x3)) or 2/3 (1-D F(2,3)) of the direct convolution's flops: "
                              "`algorithmic` is the direct-convolution rate (SURVEY 8d's 213.9 GFLOP/image figures)."})
-        for kind, key in (("wino2", "wino2d_f32"), ("wino", "wino_1d"), ("igemm", "igemm_direct"), ("gemmx6", "gemm_x6"), ("wgrad_wino2x6", "wgrad_x6"), ("wgrad_gemmx6", "wgrad_gemm_x6"), ("wgrad_wino2", "wgrad_wino2d"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
+        for kind, key in (("wino2x6", "wino2d_x6"), ("wino2h3", "wino2d_h3"), ("wino2", "wino2d_f32"), ("wino", "wino_1d"), ("igemm", "igemm_direct"), ("gemmx6", "gemm_x6"), ("wgrad_wino2x6", "wgrad_x6"), ("wgrad_gemmx6", "wgrad_gemm_x6"), ("wgrad_wino2", "wgrad_wino2d"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
             if kind in by and kind != dom_kind:
                 roof[key] = mfma_entry(kind)
         # whole step against the MFMA roof: every GEMM-shaped launch of the profiled step

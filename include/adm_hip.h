@@ -110,6 +110,18 @@ int adm_conv_fwd_wino2d_x6_up(const float* x, const void* wq6, const float* bias
                               long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                               hipStream_t stream);
 int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N);
+/* The same convolution on THREE fp16 products per f32 product (conv_wino2d_x6.hip, X6Fmt<1>): operands are split into two fp16 terms
+ * by round-to-nearest after a power-of-two scaling, s a = h0 + h1 with |s a - h0 - h1| <= 2^-24 |s a| (h1 normal), and
+ * a b ~ (h0 h0' + h0 h1' + h1 h0') / (s s').  wqh = adm_split2_f16 of the adm_pack_weight_wino2d planes with scale `wscale` (a power
+ * of two; *overflow is raised if a scaled weight leaves the fp16 range), layout [ey][cols/16][ex][term(2)][rows][16].  amax_x: a DEVICE
+ * float >= max |x| over the whole input (e.g. written by adm_gn_fwd_amax, which produced x); the kernel derives the activation scale
+ * from it so that the Winograd input transform (sums of four values) stays inside the fp16 range.  Error against fp64: that of the
+ * six-bf16-product form (tools/fp16x3_accuracy.py, tests/test_hip_ops.py).  up != 0: Conv2d(up=True) as adm_conv_fwd_wino2d_x6_up.
+ * Replaces F.conv2d of uncond_unet.py:98-110 like the other forms. */
+int adm_split2_f16(const float* src, void* dst, int rows, int cols, float scale, int* overflow, hipStream_t stream);
+int adm_conv_fwd_wino2d_h3(const float* x, const void* wqh, const float* bias, const float* res, float* y, float* ws,
+                           long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
+                           const float* amax_x, float wscale, int up, hipStream_t stream);
 /* dst (48 * rows * cols bf16, layout [ey][cols/16][ex][term][rows][16]) <- exact split a = a0 + a1 + a2 of the sixteen Winograd
  * planes src[ey * 4 + ex][rows][cols] (f32) */
 int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t stream);
@@ -245,6 +257,11 @@ int adm_gn_apply(const float* x, const float* stats, const float* gamma, const f
 int adm_gn_fwd(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
                long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
                hipStream_t stream);
+/* adm_gn_fwd that also raises the device float *amax (zeroed by the caller) to max |y| with one atomicMax per wave: the scale basis
+ * of the fp16-format convolution that consumes y (adm_conv_fwd_wino2d_h3). */
+int adm_gn_fwd_amax(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
+                    long ss_bstride, float* y, float* amax, int B, int HW, int C, int G, float eps, int silu, float drop_p,
+                    uint64_t seed, hipStream_t stream);
 /* Backward of adm_gn_apply.  Pass 1 reduces per (b,c): r1 = sum du, r2 = sum du*xhat into red[B][C][2]
  * (du = dy * mask * act'(u)); pass 2 writes dx and, when the pointers are non-NULL, dss[B][2C]
  * (d scale | d shift; row stride = ss_bstride when that is non-zero: ss and dss may be column slices of one wide buffer),

@@ -548,3 +548,115 @@ def test_schedule_kernels(ops):
         got = ops.sampler_step(dev(x), dev(cp.detach()), dev(npd.detach()), tc, tn, sched_i, sched == "const", 1.0, False)
         assert got.dtype == torch.float64
         close(got, want, rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ fp16 split format (round 3)
+def _amax(t):
+    return t.abs().max().reshape(1).to(torch.float32)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,up", [(8, 64, 96, 32, False), (4, 192, 192, 16, False), (8, 96, 64, 16, True), (2, 32, 64, 8, False),
+                                             (128, 384, 384, 4, False)])
+def test_conv_h3_forward_vs_torch(ops, monkeypatch, B, cin, cout, H, up):
+    """The 3x3 forward on THREE fp16 products per f32 product (adm_conv_fwd_wino2d_h3) against F.conv2d: plain, with the fused nearest
+    x2, with bias and residual, on the split-K shapes of the 4x4 maps -- and with a LOOSE bound (8 x the true maximum: the bound only
+    has to be an upper bound).  The launch record proves the format."""
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    x = fill.hash_tensor((B, cin, H, H), f"h3x{cin}{H}", 1.0)
+    w = fill.hash_tensor((cout, cin, 3, 3), f"h3w{cin}{cout}", 1.0 / math.sqrt(cin * 9))
+    b = fill.hash_tensor((cout,), f"h3b{cout}", 0.5)
+    Ho = 2 * H if up else H
+    r = fill.hash_tensor((B, cout, Ho, Ho), f"h3r{cout}{H}", 1.0)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    want = F.conv2d(xin, w, b, padding=1) + r
+    wd, bd = dev(w), dev(b)
+    for loose in (1.0, 8.0):
+        monkeypatch.setattr(ops, "PROFILE", [])
+        y = ops.conv2d(nhwc(x), wd, bd, nhwc(r), up=up, amax=_amax(dev(x)) * loose)
+        assert [k[0] for k in ops.PROFILE] == ["wino2h3"], [k[0] for k in ops.PROFILE]
+        close(nchw(y)[:, :cout], want)
+    assert wd._adm_packed.w2fh is not None
+    monkeypatch.setattr(ops, "FP16X3", False)          # the switch: same call, bf16 format
+    monkeypatch.setattr(ops, "PROFILE", [])
+    y6 = ops.conv2d(nhwc(x), wd, bd, nhwc(r), up=up, amax=_amax(dev(x)))
+    assert [k[0] for k in ops.PROFILE] == ["wino2x6"]
+    close(nchw(y6)[:, :cout], want)
+
+
+def test_conv_h3_error_vs_fp64(ops, monkeypatch):
+    """Accuracy of the three-fp16-product form against an fp64 convolution, next to the six-bf16-product form and the f32 MFMA kernel,
+    relative to max sum |a b|: zero-mean data, all-positive data (no cancellation), heavy-tailed activations (log-normal magnitudes over
+    ~2^17) and a single huge outlier that sets the scale for everybody else."""
+    B, C, H = 4, 384, 16
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    g = torch.Generator().manual_seed(3)
+    base = fill.hash_tensor((B, C, H, H), "h64x", 1.0)
+    cases = {"zero-mean": base, "positive": base.abs(),
+             "heavy-tailed": base * torch.exp(torch.randn(base.shape, generator=g) * 2.5),
+             "outlier": base.clone()}
+    cases["outlier"][0, 0, 0, 0] = 3.0e4
+    w = fill.hash_tensor((C, C, 3, 3), "h64w", 0.02)
+    for name, x in cases.items():
+        ww = w.abs() if name == "positive" else w
+        ref = F.conv2d(x.double(), ww.double(), padding=1)
+        scale = float(F.conv2d(x.double().abs(), ww.double().abs(), padding=1).max())
+        err = {}
+        for mode in ("f32", "x6", "h3"):
+            monkeypatch.setattr(ops, "BF16X6", mode != "f32")
+            monkeypatch.setattr(ops, "FP16X3", mode == "h3")
+            y = ops.conv2d(nhwc(x), dev(ww), None, amax=_amax(dev(x)) if mode == "h3" else None)
+            err[mode] = float((nchw(y).double() - ref).abs().max()) / scale
+        print(f"{name}: max|err| / max sum|ab|: f32 MFMA {err['f32']:.3e}, six bf16 {err['x6']:.3e}, three fp16 {err['h3']:.3e}")
+        assert err["h3"] <= max(1.5 * err["f32"], 2e-7), (name, err)
+
+
+def test_group_norm_writes_the_maximum_for_its_consumer(ops, monkeypatch):
+    """group_norm_act(..., to_conv=True) hands max |y| to the conv (a device float raised by the same kernel): exact, for the
+    register-resident small-map kernels and the multi-pass large-map path, with dropout and scale/shift; the 2x2-mean resampling keeps
+    the bound; a UNet block's convs then run on the fp16 format."""
+    for B, C, H in ((3, 192, 32), (4, 384, 16), (2, 384, 4), (2, 64, 8)):
+        x = dev(fill.hash_tensor((B, H, H, C), f"gam{C}{H}", 2.0) + 0.3)
+        gam, bet = dev(1 + fill.hash_tensor((C,), "gamg", 0.2)), dev(fill.hash_tensor((C,), "gamb", 0.1))
+        ss = dev(fill.hash_tensor((B, 2 * C), "gams", 0.5))
+        for kw in (dict(), dict(drop_p=0.1, seed=7)):
+            y = ops.group_norm_act(x, gam, bet, ss, silu=True, to_conv=True, **kw)
+            assert hasattr(y, "_adm_amax"), "no maximum attached"
+            assert float(y._adm_amax) == float(y.abs().max()), (B, C, H, kw, float(y._adm_amax), float(y.abs().max()))
+            assert ops.downsample2x(y)._adm_amax is y._adm_amax
+        y0 = ops.group_norm_act(x, gam, bet, ss, silu=True)           # not promised to a conv: no maximum
+        assert not hasattr(y0, "_adm_amax")
+    w = dev(fill.hash_tensor((192, 192, 3, 3), "gamw", 0.03))
+    x = dev(fill.hash_tensor((8, 16, 16, 192), "gamx", 1.0))
+    gam, bet = dev(torch.ones(192)), dev(torch.zeros(192))
+    monkeypatch.setattr(ops, "PROFILE", [])
+    ops.conv2d(ops.group_norm_act(x, gam, bet, None, silu=True, to_conv=True), w, None)
+    assert "wino2h3" in [k[0] for k in ops.PROFILE]
+
+
+def test_conv_h3_weights_follow_repack_all(ops, monkeypatch):
+    """The fp16 images of the Winograd operands are refreshed by the one-launch repack table, bit for bit as adm_split2_f16 would."""
+    from adm_amd import hip as _hip
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    x = fill.hash_tensor((2, 64, 8, 8), "h3rpx", 1.0)
+    w = torch.nn.Parameter(dev(fill.hash_tensor((96, 64, 3, 3), "h3rpw", 0.05)))
+    am = _amax(dev(x))
+    y0 = ops.conv2d(nhwc(x), w, None, amax=am)
+    pk = w._adm_packed
+    assert pk.w2fh is not None
+    with torch.no_grad():
+        w.data.mul_(1.5).add_(0.01)
+    ops.repack_all()
+    assert w._adm_packed is pk
+    y1 = ops.conv2d(nhwc(x), w, None, amax=am)
+    close(nchw(y1)[:, :96], F.conv2d(x, w.detach().cpu(), padding=1))
+    assert not torch.equal(y0, y1)
+    w2f, w2b = torch.empty((16, 96, 64), device=w.device), torch.empty((16, 64, 96), device=w.device)
+    _hip.call("adm_pack_weight_wino2d", w.detach().data_ptr(), w2f.data_ptr(), w2b.data_ptr(), 96, 64, 96, 64)
+    want = torch.empty_like(pk.w2fh)
+    flag = torch.zeros(1, dtype=torch.int32, device=w.device)
+    _hip.call("adm_split2_f16", w2f.data_ptr(), want.data_ptr(), 96, 64, ops.H3_WSCALE, flag.data_ptr())
+    assert torch.equal(want.view(torch.int16), pk.w2fh.view(torch.int16)) and int(flag) == 0
+    big = torch.full((16, 32, 32), 40.0, device=w.device)             # 40 * 2^11 leaves the fp16 range: the flag goes up
+    _hip.call("adm_split2_f16", big.data_ptr(), torch.empty((16, 2, 32, 32), device=w.device, dtype=torch.float16).data_ptr(), 32, 32,
+              ops.H3_WSCALE, flag.data_ptr())
+    assert int(flag) == 1
