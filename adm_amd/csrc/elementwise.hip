@@ -118,11 +118,18 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 }
 // y = a + b + c (c may be null), 16 bytes per lane: the gradient sum of a tensor with several consumers (ops.fanout)
 __global__ void add3_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, const f32x4* __restrict__ c, f32x4* __restrict__ y,
-                            long n4) {
+                            long n4, float* __restrict__ amax) {
+  float am = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 v = a[i] + b[i];
     if (c) v += c[i];
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     y[i] = v;
+  }
+  if (amax) {                                    // max |y| for a fp16-format conv that consumes the sum (conv_wino2d_x6.hip)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(am));
   }
 }
 __global__ void copy_channels_kernel(const float* __restrict__ src, int lds_, int src_off, float* __restrict__ dst,
@@ -663,10 +670,10 @@ extern "C" int adm_add(const float* a, const float* b, float* y, long n, hipStre
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
-extern "C" int adm_add3(const float* a, const float* b, const float* c, float* y, long n, hipStream_t stream) {
+extern "C" int adm_add3(const float* a, const float* b, const float* c, float* y, float* amax, long n, hipStream_t stream) {
   if (!a || !b || !y || n <= 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)y) & 15)) return ADM_EINVAL;
   hipLaunchKernelGGL(add3_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, reinterpret_cast<const f32x4*>(a),
-                     reinterpret_cast<const f32x4*>(b), reinterpret_cast<const f32x4*>(c), reinterpret_cast<f32x4*>(y), n / 4);
+                     reinterpret_cast<const f32x4*>(b), reinterpret_cast<const f32x4*>(c), reinterpret_cast<f32x4*>(y), n / 4, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

@@ -313,7 +313,7 @@ __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __res
                                  const float* __restrict__ beta, const float* __restrict__ ss, long ss_bstride,
                                  const float* __restrict__ gm, const float* __restrict__ addend,
                                  float* __restrict__ dx, int HW, int C, int G, int rows_per_split, int silu, float drop_p,
-                                 uint64_t seed) {
+                                 uint64_t seed, float* __restrict__ amax) {
   const int C4 = C >> 2, R = blockDim.x / C4;
   const int cq = threadIdx.x % C4, ry = threadIdx.x / C4;
   const int b = blockIdx.x;
@@ -339,6 +339,7 @@ __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __res
   f32x4* ob = reinterpret_cast<f32x4*>(dx + (long)b * HW * C);
   const f32x4* ab = addend ? reinterpret_cast<const f32x4*>(addend + (long)b * HW * C) : nullptr;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float am = 0.f;
 #pragma unroll 4
   for (int hw = hw0 + ry; hw < hw1; hw += R) {
     f32x4 v = xb[(long)hw * C4 + cq];
@@ -351,8 +352,11 @@ __global__ void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __res
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] *= silu_grad_f(u[k]);
     }
-    ob[(long)hw * C4 + cq] = cg * d - c1 - ((v - cm) * cr) * c2 + extra;
+    const f32x4 o = cg * d - c1 - ((v - cm) * cr) * c2 + extra;
+    am = gn_amax4(am, o);
+    ob[(long)hw * C4 + cq] = o;
   }
+  gn_amax_commit(am, amax);               // max |dx|: the data-gradient conv that consumes dx may run on the fp16 format
 }
 
 // ---------------------------------------------------------------- small feature maps: one launch per direction
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 2)) void gn_fused_bwd_ker
                                                            long ss_bstride, const float* __restrict__ addend,
                                                            float* __restrict__ dx, float* __restrict__ tot,
                                                            float* __restrict__ dss, int HW, int C, int G, int Cc, int silu,
-                                                           float drop_p, uint64_t seed) {
+                                                           float drop_p, uint64_t seed, float* __restrict__ amax) {
   extern __shared__ float sm[];                    // [R][Cc][2] partials | [Cc][2] gamma' R1, gamma' R2 | [Gc][2] m1, m2
   const int Cc4 = Cc >> 2, R = blockDim.x / Cc4, C4 = C >> 2;
   const int cq = threadIdx.x % Cc4, ry = threadIdx.x / Cc4;
@@ -567,14 +571,17 @@ __global__ __launch_bounds__(THREADS, (MAXR <= 8 ? 4 : 2)) void gn_fused_bwd_ker
   (void)g0;
   f32x4* ob = reinterpret_cast<f32x4*>(dx + (long)b * HW * C + c0);
   const f32x4* ab = addend ? reinterpret_cast<const f32x4*>(addend + (long)b * HW * C + c0) : nullptr;
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
     const int hw = ry + i * R;
     if (hw >= HW) continue;
     f32x4 o = ca * d[i] - c1 - xh[i] * c2;
     if (ab) o += ab[(long)hw * C4 + cq];
+    am = gn_amax4(am, o);
     ob[(long)hw * C4 + cq] = o;
   }
+  gn_amax_commit(am, amax);
 }
 
 // Plan of the one-launch path: slab width Cc (whole groups, whole channel quads, <= 128 channels), workgroup size and rows per
@@ -706,6 +713,10 @@ static int gn_fwd_impl(const float* x, float* stats, double* ws, const float* ga
 }
 
 // red layout: part [B][S][C][2] | tot [B][C][2] | gm [B][G][2]   (floats)
+extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                              const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma,
+                              float* dbeta, float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
+                              hipStream_t stream);
 extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                           const float* ss, long ss_bstride, float* dx, float* dss, float* dgamma, float* dbeta,
                           float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
@@ -714,10 +725,11 @@ extern "C" int adm_gn_bwd(const float* x, const float* dy, const float* stats, c
                         drop_p, seed, stream);
 }
 
-extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
-                              const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma,
-                              float* dbeta, float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
-                              hipStream_t stream) {
+static int gn_bwd_add_impl(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                           const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma,
+                           float* dbeta, float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
+                           hipStream_t stream, float* amax) {
+
   if (!x || !dy || !stats || !gamma || !beta || !dx || !red || !gn_shape_ok(B, HW, C, G)) return ADM_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return ADM_EINVAL;
   int S = adm_gn_splits(HW, C), rows = adm_cdiv(HW, S), R = gn_rows_par(C);
@@ -731,7 +743,7 @@ extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stat
     const dim3 grid(C / Cc, B), block(pl.threads);
 #define GN_BWD(MAXR, THREADS)                                                                                                   \
   hipLaunchKernelGGL((gn_fused_bwd_kernel<MAXR, THREADS>), grid, block, smf, stream, x, dy, stats, gamma, beta, ss, ss_bstride, \
-                     addend, dx, tot, dss, HW, C, G, Cc, silu, drop_p, seed)
+                     addend, dx, tot, dss, HW, C, G, Cc, silu, drop_p, seed, amax)
     if (pl.rows <= 2) GN_BWD(2, 256);
     else if (pl.rows <= 8) GN_BWD(8, 256);
     else GN_BWD(14, 256);
@@ -751,9 +763,25 @@ extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stat
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(adm_cdiv(C, 32)), dim3(256), 0, stream, tot, ss, ss_bstride, dgamma,
                        dbeta, B, C);
   hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(B, S), dim3(gn_threads(C)), 0, stream, x, dy, stats, gamma, beta, ss,
-                     ss_bstride, gm, addend, dx, HW, C, G, rows, silu, drop_p, seed);
+                     ss_bstride, gm, addend, dx, HW, C, G, rows, silu, drop_p, seed, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
+}
+
+extern "C" int adm_gn_bwd_add(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                              const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma,
+                              float* dbeta, float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
+                              hipStream_t stream) {
+  return gn_bwd_add_impl(x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx, dss, dgamma, dbeta, red, B, HW, C, G, silu, drop_p, seed,
+                         stream, nullptr);
+}
+// ... that also raises the device float *amax (zeroed by the caller) to max |dx|
+extern "C" int adm_gn_bwd_add_amax(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                                   const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma,
+                                   float* dbeta, float* red, float* amax, int B, int HW, int C, int G, int silu, float drop_p,
+                                   uint64_t seed, hipStream_t stream) {
+  return gn_bwd_add_impl(x, dy, stats, gamma, beta, ss, ss_bstride, addend, dx, dss, dgamma, dbeta, red, B, HW, C, G, silu, drop_p, seed,
+                         stream, amax);
 }
 
 // The batch reduction of d(gamma) / d(beta) for every GroupNorm layer of a backward pass in ONE launch (adm_gn_bwd / adm_gn_bwd_add

@@ -77,6 +77,7 @@ _SIGS = {
     "adm_gn_fwd_amax": [P, P, P, P, P, P, L, P, P, I, I, I, I, F, I, F, U, P],
     "adm_gn_bwd": [P, P, P, P, P, P, L, P, P, P, P, P, I, I, I, I, I, F, U, P],
     "adm_gn_bwd_add": [P, P, P, P, P, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P],
+    "adm_gn_bwd_add_amax": [P, P, P, P, P, P, L, P, P, P, P, P, P, P, I, I, I, I, I, F, U, P],
     "adm_softmax_rows": [P, L, I, L, F, P],
     "adm_posterior_sample": [P, I, P, P, I, L, I, F, P],
     "adm_attn_fwd": [P, P, P, I, I, I, P],
@@ -90,7 +91,7 @@ _SIGS = {
     "adm_silu_fwd": [P, P, L, P],
     "adm_silu_bwd": [P, P, P, L, P],
     "adm_add": [P, P, P, L, P],
-    "adm_add3": [P, P, P, P, L, P],
+    "adm_add3": [P, P, P, P, P, L, P],
     "adm_copy_channels": [P, I, I, P, I, I, L, I, F, I, P],
     "adm_spatial_att_fwd": [P, I, P, P, P, P, I, I, I, P],
     "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, P, I, I, I, P],

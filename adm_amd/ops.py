@@ -47,14 +47,22 @@ def ceil32(n: int) -> int:
 
 
 def _new(shape, like: torch.Tensor, dtype=_f32) -> torch.Tensor:
-    return torch.empty(shape, device=like.device, dtype=dtype)
+    t = torch.empty(shape, device=like.device, dtype=dtype)
+    if _grad_amax:
+        _grad_amax.pop(t.data_ptr(), None)       # (a recycled address forgets the bound of its previous tenant: see _reg_amax)
+    return t
 
 
 def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
     hip.require_cuda(t, name)
     if t.dtype != _f32:
         raise RuntimeError(f"adm_amd: {name} must be float32, got {t.dtype}")
-    return t if t.is_contiguous() else t.contiguous()
+    if t.is_contiguous():
+        return t
+    t = t.contiguous()
+    if _grad_amax:
+        _grad_amax.pop(t.data_ptr(), None)
+    return t
 
 
 # ------------------------------------------------------------------------------------------------
@@ -108,6 +116,41 @@ def _amax_slot(like: torch.Tensor) -> torch.Tensor:
     return s
 
 
+# Bounds of GRADIENT tensors travel by address: autograd hands a backward node new Python objects for its incoming gradients, so an
+# attribute set by the producing node does not arrive.  The producing node registers (address -> slot, numel, pass id); the consuming
+# conv looks its dy up; every allocation through _new() / _like() forgets the address it returns (a recycled address must not meet
+# the bound of its previous tenant), and entries of an earlier backward pass are ignored.
+_grad_amax = {}
+
+
+def _reg_amax(t: torch.Tensor, slot):
+    if slot is not None:
+        if len(_grad_amax) > 8192:
+            _grad_amax.clear()
+        _grad_amax[t.data_ptr()] = (slot, t.numel(), _graph_task_id())
+
+
+def _get_amax(t: torch.Tensor):
+    e = _grad_amax.get(t.data_ptr())
+    if e is not None and e[1] == t.numel() and e[2] == _graph_task_id() and e[2] >= 0:
+        if AMAX_CHECK:
+            got, bound = float(t.abs().max()), float(e[0])
+            if not got <= bound:
+                raise RuntimeError(f"adm_amd: registered bound {bound} of a gradient tensor is below its maximum {got}")
+        return e[0]
+    return None
+
+
+AMAX_CHECK = os.environ.get("ADM_AMAX_CHECK", "0") == "1"      # tests: verify every registered bound against the tensor it came with
+
+
+def _like(x: torch.Tensor) -> torch.Tensor:
+    t = torch.empty_like(x)
+    if _grad_amax:
+        _grad_amax.pop(t.data_ptr(), None)
+    return t
+
+
 def _h3_flag_tensor(like):
     global _h3_flag
     if _h3_flag is None or _h3_flag.device != like.device:
@@ -116,8 +159,8 @@ def _h3_flag_tensor(like):
 
 
 def _h3_operands(weight: torch.Tensor, ent: "_Packed"):
-    """fp16-format images of the 2-D Winograd operands (forward image built on first use from the f32 planes; afterwards refreshed
-    by repack_all() with the rest).  Returns the forward image."""
+    """fp16-format images of the 2-D Winograd operands (built on first use from the f32 planes; afterwards refreshed by repack_all()
+    with the rest).  Returns (forward image, data-gradient image)."""
     global _pack_table
     if ent.w2fh is None:
         co, ci = weight.shape[0], weight.shape[1]
@@ -126,9 +169,11 @@ def _h3_operands(weight: torch.Tensor, ent: "_Packed"):
         w2f, w2b = _new((16, cop, cip), w), _new((16, cip, cop), w)
         call("adm_pack_weight_wino2d", ptr(w), ptr(w2f), ptr(w2b), co, ci, cop, cip)
         ent.w2fh = torch.empty((16, 2, cop, cip), device=w.device, dtype=torch.float16)
+        ent.w2bh = torch.empty((16, 2, cip, cop), device=w.device, dtype=torch.float16)
         call("adm_split2_f16", ptr(w2f), ptr(ent.w2fh), cop, cip, H3_WSCALE, ptr(_h3_flag_tensor(w)))
-        _pack_table = None           # the one-launch repack table must learn the new destination
-    return ent.w2fh
+        call("adm_split2_f16", ptr(w2b), ptr(ent.w2bh), cip, cop, H3_WSCALE, ptr(_h3_flag_tensor(w)))
+        _pack_table = None           # the one-launch repack table must learn the new destinations
+    return ent.w2fh, ent.w2bh
 
 
 # ADM_DETERMINISTIC=1: bitwise reproducible backward.  The weight / bias gradient kernels normally combine their pixel-range
@@ -767,7 +812,7 @@ class _Conv(torch.autograd.Function):
             if h3:
                 sk = 1 if _SELECT_BATCH is not None else hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cip, cop)
                 wsk = _new((sk * B * Ho * Wo * cop,), x) if sk > 1 else None
-                call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk)), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
+                call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk)[0]), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
                      0 if wsk is None else wsk.numel(), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up))
             elif g6:
                 call("adm_gemm_x6", ptr(x), ptr(_gemm_x6_operands(pk)[0]), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
@@ -891,7 +936,7 @@ class _Conv(torch.autograd.Function):
                 if wsink is not None:
                     dst, acc = wsink, 1
                 else:
-                    dw = torch.empty_like(weight)
+                    dw = _like(weight)
                     dst, acc = dw, 0
                 if defer:
                     _defer_unpack(dwp, dst, co, ci, 0 if wino2_w else ks * ks, cip, qkv)
@@ -942,10 +987,17 @@ class _Conv(torch.autograd.Function):
             wq2 = _wino2_operands(weight, pk)[1] if (wino and _use_wino2d(B, Ho, Wo, ks, False, -1)) else None
             wq = _wino_operands(weight, pk)[1] if (wino and wq2 is None) else None
             g6 = not use_bf16 and _use_gemm_x6(B * Ho * Wo, ks, up, cip, cop)
-            kind = ("wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
+            amax_dy = _get_amax(dy) if (wq2 is not None and BF16X6 and FP16X3) else None
+            h3 = amax_dy is not None
+            kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
             with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                        f"dgrad{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
-                if g6:
+                if h3:
+                    sk = hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cop, cip)
+                    wsk = _new((sk * B * Ho * Wo * cip,), dy) if sk > 1 else None
+                    call("adm_conv_fwd_wino2d_h3", ptr(dy), ptr(_h3_operands(weight, pk)[1]), None, None, ptr(dxf), ptr(wsk),
+                         0 if wsk is None else wsk.numel(), B, Ho, Wo, cop, cop, cip, cip, cip, cip, ptr(amax_dy), H3_WSCALE, 0)
+                elif g6:
                     call("adm_gemm_x6", ptr(dy), ptr(_gemm_x6_operands(pk)[1]), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
                          cip, cip)
                 elif use_bf16:
@@ -1014,7 +1066,7 @@ class _GroupNormAct(torch.autograd.Function):
             if ssc.shape[-1] != 2 * C or ssc.shape[0] not in (1, B):
                 raise RuntimeError(f"scale/shift shape {tuple(ssc.shape)} does not match C={C}, B={B}")
             bstride = 0 if ssc.shape[0] == 1 else (ssc.stride(0) if ssc.dim() == 2 else 2 * C)
-        y = torch.empty_like(x)
+        y = _like(x)
         if out_bf16 and C % 64 == 0:
             # bf16 storage: the VALUES go to y16; `y` is only the f32 shape / dtype carrier autograd needs between this node and the
             # conv that consumes it (its storage is never written or read, and is released as soon as the conv has run)
@@ -1050,7 +1102,7 @@ class _GroupNormAct(torch.autograd.Function):
         add = None if dxr is None else _chk(dxr, "residual gradient")
         B, H, W, C = x.shape
         HW = H * W
-        dx = torch.empty_like(x)
+        dx = _like(x)
         dss = None
         slot = ctx.slot
         if ss is not None and ctx.needs_input_grad[3]:
@@ -1071,10 +1123,17 @@ class _GroupNormAct(torch.autograd.Function):
         defer = direct and DEFER_UNPACK and not DETERMINISTIC      # the batch reduction joins the end-of-backward table launch
         if defer:
             _begin_defer()
+        slot_a = _amax_slot(x) if (FP16X3 and BF16X6 and COMPUTE == "f32") else None      # max |dx| for the conv that consumes dx
         with _Prof("gn", (12.0 if add is None else 16.0) * x.numel(), f"gn-bwd B={B} HW={HW} C={C} drop={int(drop_p > 0)} (TB/s)"):
-            call("adm_gn_bwd_add", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
-                 ptr(add), ptr(dx), ptr(dss), None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(red), B, HW, C, G,
-                 int(silu), float(drop_p), seed)
+            if slot_a is not None:
+                call("adm_gn_bwd_add_amax", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
+                     ptr(add), ptr(dx), ptr(dss), None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(red), ptr(slot_a),
+                     B, HW, C, G, int(silu), float(drop_p), seed)
+            else:
+                call("adm_gn_bwd_add", ptr(x), ptr(dy), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(ss), bstride,
+                     ptr(add), ptr(dx), ptr(dss), None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(red), B, HW, C, G,
+                     int(silu), float(drop_p), seed)
+        _reg_amax(dx, slot_a)
         if defer:
             _defer_gn_param(red, B * S * C * 2, ss, bstride, dgamma, dbeta, B, C)
         if slot is not None:
@@ -1342,8 +1401,8 @@ class _Attention(torch.autograd.Function):
         qkv, out, lse = ctx.saved_tensors
         dout = _chk(dout, "dout")
         B, H, W, _ = qkv.shape
-        dqkv = torch.empty_like(qkv)
-        delta = torch.empty_like(lse)
+        dqkv = _like(qkv)
+        delta = _like(lse)
         with _Prof("attn", 10.0 * (H * W) ** 2 * 64 * B * ctx.heads):
             call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)
         return dqkv, None
@@ -1373,6 +1432,7 @@ class _Resample(torch.autograd.Function):
         if ctx.mode == 0:      # d(mean 2x2) = up * .25
             dx = _new((B, 2 * H, 2 * W, C), dy)
             call("adm_resample2x", ptr(dy), ptr(dx), B, H, W, C, 1, 0.25, 0)
+            _reg_amax(dx, _get_amax(dy))
         else:                  # d(nearest x2) = 2x2 sum
             dx = _new((B, H // 2, W // 2, C), dy)
             call("adm_resample2x", ptr(dy), ptr(dx), B, H, W, C, 0, 1.0, 0)
@@ -1412,6 +1472,11 @@ class _Concat(torch.autograd.Function):
         db = _new((*dy.shape[:-1], cb), dy)
         call("adm_copy_channels", ptr(dy), ca + cb, 0, ptr(da), ca, 0, M, ca, 1.0, 0)
         call("adm_copy_channels", ptr(dy), ca + cb, ca, ptr(db), cb, 0, M, cb, float(scale_b), 0)
+        bound = _get_amax(dy)            # max |da|, max |db| <= max |dy| (scale_b <= 1)
+        if bound is not None:
+            _reg_amax(da, bound)
+            if abs(scale_b) <= 1.0:
+                _reg_amax(db, bound)
         return da, db, None
 
 
@@ -1429,13 +1494,16 @@ class _Fanout(torch.autograd.Function):
         gs = [_chk(g, "gradient") for g in grads if g is not None]
         if not gs:
             return None, None
-        acc = gs[0]
+        acc = gs[0]                      # (a single gradient passes through with whatever bound its producer registered)
         i = 1
         while i < len(gs):
             c = gs[i + 1] if i + 1 < len(gs) else None
-            out = torch.empty_like(acc)
+            out = _like(acc)
             if acc.numel() % 4 == 0:
-                call("adm_add3", ptr(acc), ptr(gs[i]), ptr(c), ptr(out), acc.numel())
+                last = i + 2 >= len(gs)
+                slot_a = _amax_slot(acc) if (last and FP16X3 and BF16X6 and COMPUTE == "f32") else None
+                call("adm_add3", ptr(acc), ptr(gs[i]), ptr(c), ptr(out), ptr(slot_a), acc.numel())
+                _reg_amax(out, slot_a)
                 i += 2
             else:
                 call("adm_add", ptr(acc), ptr(gs[i]), ptr(out), acc.numel())
@@ -1459,7 +1527,7 @@ class _Silu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         x = _chk(x, "x")
-        y = torch.empty_like(x)
+        y = _like(x)
         call("adm_silu_fwd", ptr(x), ptr(y), x.numel())
         ctx.save_for_backward(x)
         return y
@@ -1468,7 +1536,7 @@ class _Silu(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _chk(dy, "dy")
-        dx = torch.empty_like(x)
+        dx = _like(x)
         call("adm_silu_bwd", ptr(x), ptr(dy), ptr(dx), x.numel())
         return dx
 
@@ -1492,7 +1560,7 @@ class _SpatialAtt(torch.autograd.Function):
     def forward(ctx, att, qk, h, xres):
         att, qk, h, xres = _chk(att, "att"), _chk(qk, "qk"), _chk(h, "h"), _chk(xres, "xres")
         B, H, W, C = h.shape
-        y = torch.empty_like(h)
+        y = _like(h)
         call("adm_spatial_att_fwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(xres), ptr(y), B, H * W, C)
         ctx.save_for_backward(att, qk, h)
         return y
@@ -1502,8 +1570,8 @@ class _SpatialAtt(torch.autograd.Function):
         att, qk, h = ctx.saved_tensors
         dy = _chk(dy, "dy")
         B, H, W, C = h.shape
-        dh = torch.empty_like(h)
-        datt = torch.empty_like(att)
+        dh = _like(h)
+        datt = _like(att)
         dqk = torch.zeros_like(qk)
         part = _new((B, 4), h)           # per-image partials, summed in image order (no atomics: reproducible)
         call("adm_spatial_att_bwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(dy), ptr(dh), ptr(datt), ptr(dqk), ptr(part),
@@ -1586,7 +1654,7 @@ class _PrecondOut(torch.autograd.Function):
             df = _new((B, H, W, ldf), dout)
             call("adm_precond_out_bwd", ptr(dout), ptr(s), cbs, ptr(df), ldf, B, C, H * W)
         if ctx.needs_input_grad[1]:          # the skip path c_skip * x (uncond_unet.py:631-632)
-            dx = torch.empty_like(dout)
+            dx = _like(dout)
             call("adm_axpby_b", None, 0, ptr(dout), None, ptr(a), cbs, ptr(dx), B, dout.numel() // B)
             if xdt != _f32:
                 dx = dx.to(xdt)
@@ -1604,7 +1672,7 @@ class _AxpbyB(torch.autograd.Function):
         y = _chk(y, "y")
         B = y.shape[0]
         n = y.numel() // B
-        out = torch.empty_like(y)
+        out = _like(y)
         cbs = 0 if s.numel() == 1 else 1
         call("adm_axpby_b", ptr(x), int(x.dtype == torch.float64), ptr(y), ptr(a), ptr(s), cbs, ptr(out), B, n)
         ctx.save_for_backward(s, a)
@@ -1618,10 +1686,10 @@ class _AxpbyB(torch.autograd.Function):
         B = dout.shape[0]
         dy = dx = None
         if ctx.needs_input_grad[0]:
-            dy = torch.empty_like(dout)
+            dy = _like(dout)
             call("adm_axpby_b", None, 0, ptr(dout), None, ptr(s), ctx.cbs, ptr(dy), B, dout.numel() // B)
         if ctx.needs_input_grad[1]:
-            dx = torch.empty_like(dout)
+            dx = _like(dout)
             call("adm_axpby_b", None, 0, ptr(dout), None, ptr(a), ctx.cbs, ptr(dx), B, dout.numel() // B)
             if ctx.xdt != _f32:
                 dx = dx.to(ctx.xdt)
@@ -1702,7 +1770,7 @@ def posterior_sample(moments, C: int, eps=None, zscale: float = 1.0):
 def q_sample(x0, noise, t, schedule: int):
     x0, noise, t = _chk(x0, "x0"), _chk(noise, "noise"), _chk(t, "t")
     B = x0.shape[0]
-    xt = torch.empty_like(x0)
+    xt = _like(x0)
     call("adm_q_sample", ptr(x0), ptr(noise), ptr(t), ptr(xt), B, x0.numel() // B, schedule)
     return xt
 
@@ -1716,7 +1784,7 @@ class _DdmLoss(torch.autograd.Function):
         B = c_pred.shape[0]
         n = c_pred.numel() // B
         per = _new((B,), c_pred)
-        dc, dn = torch.empty_like(c_pred), torch.empty_like(n_pred)
+        dc, dn = _like(c_pred), _like(n_pred)
         call("adm_ddm_loss", ptr(c_pred), ptr(n_pred), ptr(x0), ptr(noise), ptr(w), ptr(per), ptr(dc), ptr(dn), 1.0 / B,
              B, n)
         ctx.save_for_backward(dc, dn)
@@ -1743,7 +1811,7 @@ class _DdmLossLatent(torch.autograd.Function):
         B = c_pred.shape[0]
         n = c_pred.numel() // B
         per, l1 = _new((B,), c_pred), _new((B,), c_pred)
-        dc, dn = torch.empty_like(c_pred), torch.empty_like(n_pred)
+        dc, dn = _like(c_pred), _like(n_pred)
         call("adm_ddm_loss_latent", ptr(c_pred), ptr(n_pred), ptr(x0), ptr(noise), ptr(xt), ptr(t), ptr(w), ptr(per),
              ptr(l1), ptr(dc), ptr(dn), 1.0 / B, B, n, int(schedule), int(use_l1))
         ctx.save_for_backward(dc, dn)

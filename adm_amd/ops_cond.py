@@ -9,7 +9,7 @@ import torch
 
 from . import hip, ops
 from .hip import call, ptr
-from .ops import _chk, _direct_grad, _new, _notify, _Prof, ceil32, packed
+from .ops import _chk, _direct_grad, _like, _new, _notify, _Prof, ceil32, packed
 
 _f32 = torch.float32
 
@@ -22,7 +22,7 @@ class _WeightStd(torch.autograd.Function):
     def forward(ctx, w):
         w = _chk(w, "weight")
         O, K = w.shape[0], w[0].numel()
-        wn = torch.empty_like(w)
+        wn = _like(w)
         stats = _new((O, 2), w)
         call("adm_ws_fwd", ptr(w), ptr(wn), ptr(stats), O, K, 1e-5)
         ctx.save_for_backward(w, stats)
@@ -32,7 +32,7 @@ class _WeightStd(torch.autograd.Function):
     def backward(ctx, dwn):
         w, stats = ctx.saved_tensors
         dwn = _chk(dwn, "dwn")
-        dw = torch.empty_like(w)
+        dw = _like(w)
         call("adm_ws_bwd", ptr(w), ptr(stats), ptr(dwn), ptr(dw), w.shape[0], w[0].numel(), 0)
         return dw
 
@@ -106,7 +106,7 @@ class _ConvGeneric(torch.autograd.Function):
                 call("adm_unpack_wgrad", ptr(dwp), ptr(sink), co, ci, ks, cop, cip, 0, 1)
                 _notify(weight)
             else:
-                dw = torch.empty_like(weight)
+                dw = _like(weight)
                 call("adm_unpack_wgrad", ptr(dwp), ptr(dw), co, ci, ks, cop, cip, 0, 0)
             if need_b:
                 bsink = _direct_grad(bias)
@@ -142,7 +142,7 @@ class _LayerNormC(torch.autograd.Function):
         gv = _chk(g.detach().reshape(-1), "g")
         if gv.numel() != C:
             raise RuntimeError(f"LayerNorm gain has {gv.numel()} entries, the tensor {C} channels")
-        y = torch.empty_like(x)
+        y = _like(x)
         call("adm_lnc_fwd", ptr(x), ptr(gv), ptr(y), x.numel() // C, C, 1e-5)
         ctx.save_for_backward(x, g)
         return y
@@ -153,10 +153,10 @@ class _LayerNormC(torch.autograd.Function):
         dy = _chk(dy, "dy")
         C = x.shape[-1]
         M = x.numel() // C
-        dx = torch.empty_like(x)
+        dx = _like(x)
         part = _new((hip.lib().adm_lnc_blocks(M) * C,), x, torch.float64)
         sink = _direct_grad(g)
-        dg = sink if sink is not None else torch.empty_like(g)
+        dg = sink if sink is not None else _like(g)
         call("adm_lnc_bwd", ptr(x), ptr(dy), ptr(g.detach()), ptr(dx), ptr(dg), ptr(part), M, C, 1e-5, int(sink is not None))
         if sink is not None:
             _notify(g)
@@ -177,7 +177,7 @@ class _BatchNorm(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         mr = _new((C, 2), x)
-        y = torch.empty_like(x)
+        y = _like(x)
         part = _new((hip.lib().adm_bn_blocks(M) * 2 * C,), x, torch.float64) if training else None
         call("adm_bn_fwd", ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(run_mean), ptr(run_var), ptr(mr), ptr(y), ptr(part),
              M, C, float(eps), float(momentum), int(training))
@@ -191,13 +191,13 @@ class _BatchNorm(torch.autograd.Function):
         dy = _chk(dy, "dy")
         C = x.shape[-1]
         M = x.numel() // C
-        dx = torch.empty_like(x)
+        dx = _like(x)
         part = _new((hip.lib().adm_bn_blocks(M) * 2 * C,), x, torch.float64)
         sums = _new((2 * C,), x)
         sg, sb = _direct_grad(gamma), _direct_grad(beta)
         direct = sg is not None and sb is not None
-        dg = sg if direct else torch.empty_like(gamma)
-        db = sb if direct else torch.empty_like(beta)
+        dg = sg if direct else _like(gamma)
+        db = sb if direct else _like(beta)
         call("adm_bn_bwd", ptr(x), ptr(dy), ptr(mr), ptr(gamma.detach()), ptr(dx), ptr(dg), ptr(db), ptr(part), ptr(sums), M, C,
              int(ctx.training), int(direct))
         if direct:
@@ -257,7 +257,7 @@ class _Act(torch.autograd.Function):
         x = _chk(x, "x")
         if x.numel() % 4:
             raise RuntimeError("activation tensors must have a multiple of 4 elements")
-        y = torch.empty_like(x)
+        y = _like(x)
         call("adm_act_fwd", ptr(x), ptr(y), x.numel(), act, float(drop_p), int(seed))
         ctx.save_for_backward(x)
         ctx.meta = (act, drop_p, seed)
@@ -268,7 +268,7 @@ class _Act(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         act, drop_p, seed = ctx.meta
         dy = _chk(dy, "dy")
-        dx = torch.empty_like(x)
+        dx = _like(x)
         call("adm_act_bwd", ptr(x), ptr(dy), ptr(dx), x.numel(), act, float(drop_p), int(seed))
         return dx, None, None, None
 
@@ -299,7 +299,7 @@ class _Add(torch.autograd.Function):
         a, b = _chk(a, "a"), _chk(b, "b")
         if a.shape != b.shape:
             raise RuntimeError(f"add: shapes {tuple(a.shape)} and {tuple(b.shape)} differ")
-        y = torch.empty_like(a)
+        y = _like(a)
         call("adm_add", ptr(a), ptr(b), ptr(y), a.numel())
         return y
 
@@ -336,7 +336,7 @@ class _MHA(torch.autograd.Function):
         B, Lq, C = q.shape
         Lk = k.shape[1]
         D = C // heads
-        o = torch.empty_like(q)
+        o = _like(q)
         lse = _new((B * heads, Lq), q)
         call("adm_mha_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, Lq, Lk, heads, D, C, C, C, C, float(scale))
         ctx.save_for_backward(q, k, v, o, lse)
@@ -350,8 +350,8 @@ class _MHA(torch.autograd.Function):
         do = _chk(do, "do")
         B, Lq, C = q.shape
         Lk = k.shape[1]
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        delta = torch.empty_like(lse)
+        dq, dk, dv = _like(q), _like(k), _like(v)
+        delta = _like(lse)
         call("adm_mha_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta), B, Lq, Lk,
              heads, C // heads, C, C, C, C, C, C, C, float(scale))
         return dq, dk, dv, None, None
@@ -386,8 +386,8 @@ class _SelfAttnPacked(torch.autograd.Function):
         do = _chk(do, "do")
         B, L, C3 = qkv.shape
         C = C3 // 3
-        dqkv = torch.empty_like(qkv)
-        delta = torch.empty_like(lse)
+        dqkv = _like(qkv)
+        delta = _like(lse)
         base, dbase = qkv.data_ptr(), dqkv.data_ptr()
         P = hip.c_void_p
         call("adm_mha_bwd", P(base), P(base + 4 * C), P(base + 8 * C), ptr(o), ptr(do), ptr(lse), P(dbase), P(dbase + 4 * C),
@@ -421,8 +421,8 @@ class _LinearAttention(torch.autograd.Function):
         qkv, cx, kst = ctx.saved_tensors
         dout = _chk(dout, "dout")
         B, N, _ = qkv.shape
-        dqkv = torch.empty_like(qkv)
-        dctx = torch.empty_like(cx)
+        dqkv = _like(qkv)
+        dctx = _like(cx)
         S = _new((B, 128), qkv)
         ws = _new((hip.lib().adm_linattn_ws_floats(B, N),), qkv)
         call("adm_linattn_bwd", ptr(qkv), ptr(dout), ptr(cx), ptr(kst), ptr(dqkv), ptr(dctx), ptr(S), ptr(ws), B, N)
@@ -438,7 +438,7 @@ class _SpatialAttBig(torch.autograd.Function):
     def forward(ctx, att, qk, h, xres):
         att, qk, h, xres = _chk(att, "att"), _chk(qk, "qk"), _chk(h, "h"), _chk(xres, "xres")
         B, H, W, C = h.shape
-        y = torch.empty_like(h)
+        y = _like(h)
         gate = _new((B, H * W, 2), h)
         call("adm_spatial_att_big_fwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(xres), ptr(y), ptr(gate), B, H * W, C)
         ctx.save_for_backward(att, qk, h, gate)
@@ -449,7 +449,7 @@ class _SpatialAttBig(torch.autograd.Function):
         att, qk, h, gate = ctx.saved_tensors
         dy = _chk(dy, "dy")
         B, H, W, C = h.shape
-        dh, datt = torch.empty_like(h), torch.empty_like(att)
+        dh, datt = _like(h), _like(att)
         dqk = torch.zeros_like(qk)
         part = _new((B, 4), h)
         call("adm_spatial_att_big_bwd", ptr(att), att.shape[-1], ptr(qk), ptr(h), ptr(dy), ptr(gate), ptr(dh), ptr(datt), ptr(dqk),

@@ -283,6 +283,12 @@ int adm_gn_bwd_param_table(const long* table, int rows, long total_blocks, hipSt
 int adm_gn_bwd_add(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                    const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma, float* dbeta,
                    float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);
+/* ... that also raises the device float *amax (zeroed by the caller) to max |dx|: the data-gradient convolution that consumes dx
+ * can then run on the fp16 format (adm_conv_fwd_wino2d_h3 with the data-gradient weight image). */
+int adm_gn_bwd_add_amax(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                        const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma, float* dbeta,
+                        float* red, float* amax, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed,
+                        hipStream_t stream);
 
 /* ---------------- KL autoencoder (first stage) helpers ---------------------------------------- */
 
@@ -337,7 +343,7 @@ int adm_add(const float* a, const float* b, float* y, long n, hipStream_t stream
 /* y = a + b (+ c when non-NULL), n % 4 == 0, 16-byte aligned: the sum of the gradients autograd would otherwise add pairwise for a
  * tensor with several consumers -- the encoder outputs feed the next block and both decoders' concatenations
  * (uncond_unet.py:548-571). */
-int adm_add3(const float* a, const float* b, const float* c, float* y, long n, hipStream_t stream);
+int adm_add3(const float* a, const float* b, const float* c, float* y, float* amax, long n, hipStream_t stream);     /* amax (may be NULL): raised to max |y| */
 /* dst[m][dst_off + c] (+)= scale * src[m][src_off + c], c < C: channel concat / slice copies
  * (torch.cat, :571, :578; `scale` carries uncond_unet_sd_3's skip-tuning ratio) */
 int adm_copy_channels(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,

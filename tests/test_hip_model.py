@@ -395,3 +395,34 @@ def test_affine_group_equals_per_block_linears(gpu, monkeypatch):
             assert err <= (2e-4 if ("affine" in n or "map_" in n) else 1e-3), (rnd, n, err)
     assert not torch.equal(res[True][0][0][0], res[True][0][1][0]) and not torch.equal(res[True][0][1][0], res[True][0][2][0])
     close(res[True][1][0], res[False][1][0], rtol=1e-5, atol=1e-6)
+
+
+def test_fp16_split_format_in_the_training_step(gpu, monkeypatch):
+    """The fp16 split format end to end on the reduced two-decoder UNet (every 3x3 layer forced onto the Winograd kernels): the forward
+    convs take their bound from the GroupNorm that feeds them, the data-gradient convs from the GroupNorm backward / gradient sum /
+    concatenation split that produced their dy (ops._reg_amax / _get_amax, by address); with ADM_AMAX_CHECK semantics on, EVERY bound
+    that reaches a conv is verified against the tensor it came with.  Outputs and all parameter gradients equal the bf16-format run."""
+    from adm_amd import ops
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    res = {}
+    for h3 in (False, True):
+        monkeypatch.setattr(ops, "FP16X3", h3)
+        monkeypatch.setattr(ops, "AMAX_CHECK", h3)
+        m, cfg, _ = build_unet("uncond_unet", gpu)
+        m.train()
+        x, sigma, aug = small_inputs(cfg)
+        monkeypatch.setattr(ops, "PROFILE", [])
+        dx, dy = m(x.to(gpu), sigma.to(gpu), augment_labels=aug.to(gpu))
+        gx, gy = fill.hash_tensor(dx.shape, "gx", 1.0).to(gpu), fill.hash_tensor(dy.shape, "gy", 1.0).to(gpu)
+        ((dx * gx).sum() + (dy * gy).sum()).backward()
+        tags = [r[4] for r in ops.PROFILE if r[0] == "wino2h3"]
+        monkeypatch.setattr(ops, "PROFILE", None)
+        res[h3] = (dx.detach().clone(), dy.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}, tags)
+    tags = res[True][3]
+    n_fwd, n_dgrad = sum(t.startswith("fwd") for t in tags), sum(t.startswith("dgrad") for t in tags)
+    assert not res[False][3] and n_fwd >= 40 and n_dgrad >= 40, (n_fwd, n_dgrad)
+    close(res[True][0], res[False][0], rtol=1e-5, atol=1e-5); close(res[True][1], res[False][1], rtol=1e-5, atol=1e-5)
+    gmax = max(float(g.double().norm()) for g in res[False][2].values())
+    for n, g in res[False][2].items():
+        err = float((res[True][2][n].double() - g.double()).norm() / (g.double().norm() + 1e-6 * gmax))
+        assert err <= 2e-4, (n, err)
