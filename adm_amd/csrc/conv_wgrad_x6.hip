@@ -43,6 +43,7 @@ struct WxP {
   long split_stride, bias_stride;      // > 0: deterministic mode, partials of split z at dwp + z * split_stride (plain stores)
   int up;                              // 1: x is [B][H/2][W/2][ldx], the conv ran on its nearest x2 up-sampling (Conv2d(up=True))
   int tiles;                           // (cout tiles) x (cin tiles): the grid is tiles x passes x splits, one-dimensional
+  const float* amax_x; const float* amax_dy;     // FMT 1 only: device upper bounds of |x| and |dy| (the per-tensor scales come from them)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -52,7 +53,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int XT = 64, XK = 16;                    // 64 x 64 channel tile, 16 tiles (2x2 pixels each) per stage
 constexpr int XROW = 96;                           // bf16 elements per LDS row: 64 channels + 32 of padding (192 bytes)
-constexpr int X_IMG = 4 * 3 * XK * XROW;           // one operand image of a stage: [4 ex][3 terms][16 tiles][XROW] = 36 KB
+// FMT 0: three bf16 terms by truncation, six products.  FMT 1: s v = h0 + h1, two fp16 terms (round to nearest), s a power of two
+// from an upper bound of the tensor's |v| (conv_wino2d_x6.hip: s max|v| <= 16000, the transforms' sums of four stay finite); three
+// products (h0 h0' + h0 h1' + h1 h0'), the scales undone once in the epilogue.  Same accuracy (tools/fp16x3_accuracy.py).
+template <int FMT> struct XFmt {
+  static constexpr int TERMS = FMT ? 2 : 3;
+  static constexpr int IMG = 4 * TERMS * XK * XROW;     // one operand image of a stage: [4 ex][TERMS][16 tiles][XROW] = 36 / 24 KB
+};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ inline float xh3_scale(float amax) {       // = h3_scale of conv_wino2d_x6.hip
+  if (!(amax > 0.f) || !(amax < 3e38f)) return 1.f;
+  int e;
+  frexpf(16000.f / amax, &e);
+  return ldexpf(1.f, e - 1);
+}
 
 // All the arithmetic next to the MFMAs is written with PLAIN (one value per lane) f32 instructions: tools/overlap_probe2.hip
 // measures v_add_f32 / v_and_b32 / v_perm_b32 of another wave 91-96 % hidden behind v_mfma_f32_32x32x16_bf16 on the same SIMD, and
@@ -85,7 +100,29 @@ __device__ __forceinline__ f32x4 fma4s(f32x4 a, f32x4 b, f32x2 sgn) {
   for (int i = 0; i < 4; ++i) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r[i]) : "v"(b[i]), "v"(sgn[0]), "v"(a[i]));
   return r;
 }
-__device__ __forceinline__ void store_planes(const f32x4 (&v)[4], unsigned short* l) {
+__device__ __forceinline__ void split2x(const f32x4 v, float s, u32x2& t0, u32x2& t1) {
+  _Float16 h0[4], h1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float vs = v[i] * s;
+    h0[i] = (_Float16)vs;
+    h1[i] = (_Float16)(vs - (float)h0[i]);
+  }
+  t0 = u32x2{__builtin_bit_cast(unsigned, f16x2{h0[0], h0[1]}), __builtin_bit_cast(unsigned, f16x2{h0[2], h0[3]})};
+  t1 = u32x2{__builtin_bit_cast(unsigned, f16x2{h1[0], h1[1]}), __builtin_bit_cast(unsigned, f16x2{h1[2], h1[3]})};
+}
+template <int FMT>
+__device__ __forceinline__ void store_planes(const f32x4 (&v)[4], unsigned short* l, float s) {
+  if (FMT) {
+#pragma unroll
+    for (int ex = 0; ex < 4; ++ex) {
+      u32x2 t0, t1;
+      split2x(v[ex], s, t0, t1);
+      *reinterpret_cast<u32x2*>(l + (ex * 2 + 0) * XK * XROW) = t0;
+      *reinterpret_cast<u32x2*>(l + (ex * 2 + 1) * XK * XROW) = t1;
+    }
+    return;
+  }
 #pragma unroll
   for (int ex = 0; ex < 4; ++ex) {
     u32x2 t0, t1, t2;
@@ -105,8 +142,11 @@ __device__ __forceinline__ void lds_barrier() {    // waits for this wave's LDS 
 // images, reads and MFMAs with the four `ex` planes of a stage holding four consecutive 16-pixel chunks (64 pixels per stage, no
 // transforms, gridDim.y = 1); the epilogue adds the four accumulators.
 // XBF: x holds bf16 (the bf16-storage activations of the opt-in bf16 mode): 8-byte loads, widened in the producer
-template <int MODE, bool XBF>
+template <int MODE, bool XBF, int FMT>
 __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
+  constexpr int X_IMG = XFmt<FMT>::IMG, TERMS = XFmt<FMT>::TERMS;
+  float s_x = 1.f, s_dy = 1.f;
+  if (FMT) { s_x = xh3_scale(*p.amax_x); s_dy = xh3_scale(*p.amax_dy); }
   extern __shared__ __attribute__((aligned(16))) unsigned short smx[];
   unsigned short* As = smx;                        // [2][X_IMG]  dY side: rows = tiles, columns = couts
   unsigned short* Bs = smx + 2 * X_IMG;            // [2][X_IMG]  X side:  rows = tiles, columns = cins
@@ -232,10 +272,10 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
         if (do_bias) bsum = add4x(bsum, add4x(add4x(u0[d][0], u0[d][1]), add4x(u0[d][2], u0[d][3])));
         if (x_side && XBF) {
           const f32x4 w[4] = {wide4(u0[d][0]), wide4(u0[d][1]), wide4(u0[d][2]), wide4(u0[d][3])};
-          store_planes(w, lb + slot * X_IMG);
+          store_planes<FMT>(w, lb + slot * X_IMG, s_x);
           return;
         }
-        store_planes(u0[d], (x_side ? lb : la) + slot * X_IMG);
+        store_planes<FMT>(u0[d], (x_side ? lb : la) + slot * X_IMG, x_side ? s_x : s_dy);
         return;
       }
       if (!x_side) {
@@ -243,14 +283,14 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const f32x4 a[4] = {e[0], add4x(e[0], e[1]), sub4x(e[0], e[1]), sub4x(zero, e[1])};
         if (do_bias) bsum = add4x(bsum, a[1]);
-        store_planes(a, la + slot * X_IMG);
+        store_planes<FMT>(a, la + slot * X_IMG, s_dy);
         return;
       }
       f32x4 dd[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) dd[j] = fma4s(wide4(u0[d][j]), wide4(u1[d][j]), sgn);     // rows iA +- iB; the pass ey = 2 wants iB - iA: the epilogue negates
       const f32x4 b[4] = {sub4x(dd[0], dd[2]), add4x(dd[1], dd[2]), sub4x(dd[2], dd[1]), sub4x(dd[1], dd[3])};
-      store_planes(b, lb + slot * X_IMG);
+      store_planes<FMT>(b, lb + slot * X_IMG, s_x);
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) issue(d, d);
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   // transposed fragment read: 16-lane group g, lane i = 4 q + p of it: row (tile) 8 (g >> 1) + q [+ 4 for the second read],
   // columns 16 (g & 1) + 4 p .. + 3 of a 32-channel block; the lane receives channel 16 (g & 1) + i of those four tiles
   const int g = lane >> 4, gi = lane & 15;
-  const int foff = (8 * (g >> 1) + (gi >> 2)) * XROW + 16 * (g & 1) + 4 * (gi & 3) + wid * 3 * XK * XROW;
+  const int foff = (8 * (g >> 1) + (gi >> 2)) * XROW + 16 * (g & 1) + 4 * (gi & 3) + wid * TERMS * XK * XROW;
   f32x16 tot[2][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -316,11 +356,11 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const unsigned short* Ab = As + (s & 1) * X_IMG + foff;
     const unsigned short* Bb = Bs + (s & 1) * X_IMG + foff;
-    bf16x8 a[2][3], b[2][3];
+    bf16x8 a[2][TERMS], b[2][TERMS];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < TERMS; ++k) {
         if (XW_ABL & 16) {
           struct { s16x4 lo, hi; } fk = {{(short)0x3f80, (short)s, (short)0x3f80, (short)h}, {(short)0x3f00, (short)k, (short)0x3f00, (short)lane}};
           a[h][k] = __builtin_bit_cast(bf16x8, fk); b[h][k] = a[h][k];
@@ -333,11 +373,21 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        if (XW_ABL & 8) { tot[mb][nb][0] += (float)(__builtin_bit_cast(s16x4, __builtin_bit_cast(u32x2, *(u32x2*)&a[mb][0]))[0] ^ __builtin_bit_cast(s16x4, *(u32x2*)&b[nb][2])[1]); continue; }
+        if (XW_ABL & 8) { tot[mb][nb][0] += (float)(__builtin_bit_cast(s16x4, __builtin_bit_cast(u32x2, *(u32x2*)&a[mb][0]))[0] ^ __builtin_bit_cast(s16x4, *(u32x2*)&b[nb][TERMS - 1])[1]); continue; }
+        if (FMT) {                                 // three products from C = 0 (small ones first), then the one rounded add
+          const f16x8 a0 = __builtin_bit_cast(f16x8, a[mb][0]), a1 = __builtin_bit_cast(f16x8, a[mb][1]);
+          const f16x8 b0 = __builtin_bit_cast(f16x8, b[nb][0]), b1 = __builtin_bit_cast(f16x8, b[nb][1]);
+          f32x16 c;
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a0), "v"(b1));
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+          tot[mb][nb] += c;
+          continue;
+        }
         // six products of this stage from C = 0 (small ones first), then ONE rounded f32 add into the running total
         f32x16 c;                                  // C = the inline constant 0 (the builtin with a zero vector first copies sixteen zeros)
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a[mb][0]), "v"(b[nb][2]));
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][2], b[nb][0], c, 0, 0, 0);
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a[mb][0]), "v"(b[nb][TERMS - 1]));
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][TERMS - 1], b[nb][0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][1], b[nb][1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][0], b[nb][1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][1], b[nb][0], c, 0, 0, 0);
@@ -356,7 +406,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the images (and the bias scratch)
   {
     const int lr = lane & 31, lh = lane >> 5;
-    const float osgn = (MODE == 0 && ey == 2) ? -1.f : 1.f;      // the X side of the pass ey = 2 was produced negated
+    const float osgn = ((MODE == 0 && ey == 2) ? -1.f : 1.f) / (s_x * s_dy);   // the X side of the pass ey = 2 was produced negated; FMT 1: powers of two out
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -391,16 +441,40 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   }
 }
 
+// amax_x / amax_dy both non-null: the fp16 format (FMT 1) with scales from these device bounds (f32 activations only)
 int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int xbf = 0);
+                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int xbf = 0,
+                  const float* amax_x = nullptr, const float* amax_dy = nullptr);
+
+template <int MODE>
+int wgrad_x6_launch(const WxP& p, dim3 grid, int xbf, int fmt, hipStream_t stream) {
+  static bool attr_set = false;
+  constexpr int smem0 = 4 * XFmt<0>::IMG * (int)sizeof(unsigned short), smem1 = 4 * XFmt<1>::IMG * (int)sizeof(unsigned short);
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess)
+      return ADM_ELAUNCH;
+    attr_set = true;
+  }
+  if (fmt) hipLaunchKernelGGL((wgrad_x6_kernel<MODE, false, 1>), grid, dim3(768), smem1, stream, p);
+  else if (xbf) hipLaunchKernelGGL((wgrad_x6_kernel<MODE, true, 0>), grid, dim3(768), smem0, stream, p);
+  else hipLaunchKernelGGL((wgrad_x6_kernel<MODE, false, 0>), grid, dim3(768), smem0, stream, p);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
 
 // MODE 1 host side: P pixels, no geometry
 int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
-                      bool det, bool plan_only, hipStream_t stream, int xbf = 0);
+                      bool det, bool plan_only, hipStream_t stream, int xbf = 0, const float* amax_x = nullptr,
+                      const float* amax_dy = nullptr);
 
 int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
-                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int xbf) {
+                  int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int xbf, const float* amax_x,
+                  const float* amax_dy) {
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
+  const int fmt = amax_x != nullptr && amax_dy != nullptr;
+  if ((amax_x != nullptr) != (amax_dy != nullptr) || (fmt && xbf)) return ADM_EINVAL;
   if (B <= 0 || H < 2 || W < 2) return ADM_EINVAL;
   if ((Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
   if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
@@ -408,7 +482,7 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   const int lw = ilog2(W), lh = ilog2(H);
   if (lw < 1 || lh < 1) return ADM_EINVAL;                    // power-of-two H, W (>= 2) only
   WxP p;
-  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
+  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias; p.amax_x = amax_x; p.amax_dy = amax_dy;
   const long P = (long)B * H * W;
   const long xb = (up ? P / 4 : P) * ldx * (xbf ? 2 : 4), db = P * lddy * 4;
   if (xb >= (1L << 31) - (1L << 22) || db >= (1L << 31) - (1L << 22)) return ADM_EINVAL;   // 32-bit offsets
@@ -440,33 +514,21 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
   if (p.atomic && !prezeroed && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 12 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
-  constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess)
-      return ADM_ELAUNCH;
-    attr_set = true;
-  }
   p.tiles = adm_cdiv(Cout, XT) * p.tilesN;
-  dim3 grid(p.tiles * 4 * splits);
-  if (xbf) hipLaunchKernelGGL((wgrad_x6_kernel<0, true>), grid, dim3(768), smem, stream, p);
-  else hipLaunchKernelGGL((wgrad_x6_kernel<0, false>), grid, dim3(768), smem, stream, p);
-  ADM_CHECK_LAUNCH();
-  return ADM_OK;
+  return wgrad_x6_launch<0>(p, dim3(p.tiles * 4 * splits), xbf, fmt, stream);
 }
 
 int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
-                      bool det, bool plan_only, hipStream_t stream, int xbf) {
+                      bool det, bool plan_only, hipStream_t stream, int xbf, const float* amax_x, const float* amax_dy) {
   if (!plan_only && (!x || !dy || !dwp)) return ADM_EINVAL;
+  const int fmt = amax_x != nullptr && amax_dy != nullptr;
+  if ((amax_x != nullptr) != (amax_dy != nullptr) || (fmt && xbf)) return ADM_EINVAL;
   if (P <= 0 || (Cin & 31) || (Cout & 31) || (ldx & 3) || (lddy & 3)) return ADM_EINVAL;
   if (!plan_only && (((uintptr_t)x | (uintptr_t)dy) & 15)) return ADM_EINVAL;
   const long xb = P * ldx * (xbf ? 2 : 4), db = P * lddy * 4;
   if (P >= (1L << 30) || xb >= (1L << 31) || db >= (1L << 31)) return ADM_EINVAL;
   WxP p;
-  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias;
+  p.x = x; p.dy = dy; p.dwp = dwp; p.dbias = dbias; p.amax_x = amax_x; p.amax_dy = amax_dy;
   p.Pp = (int)P; p.H = 0; p.W = 0; p.lw = 0; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.up = 0;
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, XT);
@@ -493,22 +555,8 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
   if (p.atomic && !prezeroed && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
-  constexpr int smem = 4 * X_IMG * (int)sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess)
-      return ADM_ELAUNCH;
-    attr_set = true;
-  }
   p.tiles = adm_cdiv(Cout, XT) * p.tilesN;
-  dim3 grid(p.tiles * splits);
-  if (xbf) hipLaunchKernelGGL((wgrad_x6_kernel<1, true>), grid, dim3(768), smem, stream, p);
-  else hipLaunchKernelGGL((wgrad_x6_kernel<1, false>), grid, dim3(768), smem, stream, p);
-  ADM_CHECK_LAUNCH();
-  return ADM_OK;
+  return wgrad_x6_launch<1>(p, dim3(p.tiles * splits), xbf, fmt, stream);
 }
 
 }  // namespace
@@ -560,4 +608,20 @@ extern "C" int adm_conv_wgrad_x6_bf16a(const void* x16, const float* dy, float* 
 extern "C" int adm_gemm_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout,
                                        int lddy, int splits, hipStream_t stream) {
   return wgrad_x6_1x1_impl(static_cast<const float*>(x16), dy, dwp, dbias, P, Cin, ldx, Cout, lddy, splits, false, false, stream, 1);
+}
+
+// The same kernels on the fp16 format (FMT 1 above): amax_x / amax_dy = device floats, upper bounds of |x| and |dy| (the producers of
+// the two tensors wrote them: adm_gn_fwd_amax, adm_gn_bwd_add_amax, adm_add3).  A bound that is too small overflows the fp16 terms
+// (inf / nan in dW: loud, not silent).  det != 0: the deterministic workspace mode of adm_conv_wgrad_x6_ws / adm_gemm_wgrad_x6_ws
+// (dwp = ws, dbias = bws, splits from the _plan call); else splits as for adm_conv_wgrad_x6.
+extern "C" int adm_conv_wgrad_x6_h3(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx,
+                                    int Cout, int lddy, int splits, int up, int det, const float* amax_x, const float* amax_dy,
+                                    hipStream_t stream) {
+  if (!amax_x || !amax_dy) return ADM_EINVAL;
+  return wgrad_x6_impl(x, dy, dwp2, dbias, B, H, W, Cin, ldx, Cout, lddy, splits, det != 0, false, up ? 1 : 0, stream, 0, amax_x, amax_dy);
+}
+extern "C" int adm_gemm_wgrad_x6_h3(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout,
+                                    int lddy, int splits, int det, const float* amax_x, const float* amax_dy, hipStream_t stream) {
+  if (!amax_x || !amax_dy) return ADM_EINVAL;
+  return wgrad_x6_1x1_impl(x, dy, dwp, dbias, P, Cin, ldx, Cout, lddy, splits, det != 0, false, stream, 0, amax_x, amax_dy);
 }

@@ -45,6 +45,8 @@ _SIGS = {
     "adm_gemm_wgrad_x6": [P, P, P, P, L, I, I, I, I, I, P],
     "adm_gemm_wgrad_x6_ws": [P, P, P, P, L, I, I, I, I, I, P],
     "adm_gemm_wgrad_x6_plan": [L, I, I],
+    "adm_conv_wgrad_x6_h3": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, P],
+    "adm_gemm_wgrad_x6_h3": [P, P, P, P, L, I, I, I, I, I, I, P, P, P],
     "adm_conv_wgrad_x6_bf16a": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "adm_gemm_wgrad_x6_bf16a": [P, P, P, P, L, I, I, I, I, I, P],
     "adm_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],

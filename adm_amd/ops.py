@@ -98,6 +98,7 @@ BF16X6 = os.environ.get("ADM_BF16X6", "1") != "0"
 # that repack_all() reads every 64 steps and that switches the format off (never observed: it takes a Winograd-domain weight >= 32).
 # ADM_FP16X3=0 keeps every split kernel on the bf16 format.
 FP16X3 = os.environ.get("ADM_FP16X3", "1") != "0"
+H3_WGRAD = os.environ.get("ADM_FP16X3_WGRAD", "1") != "0"      # ... also for the weight gradients
 H3_WSCALE = 2048.0
 _h3_flag = None             # device int32: raised by the weight split kernels on overflow
 _h3_checks = 0
@@ -826,6 +827,7 @@ class _Conv(torch.autograd.Function):
         ctx.save_for_backward(x16 if x16 is not None else x, weight, bias)      # (the carrier is not kept)
         _mark_uses(ctx, (1, weight), (2, bias))
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
+        ctx.amax_x = amax if (FP16X3 and BF16X6 and not bf16) else None       # the weight gradient reads x on the same format
         return y
 
     @staticmethod
@@ -903,7 +905,11 @@ class _Conv(torch.autograd.Function):
                 else:
                     dwp = _new((cop, planes * cip), dy)
                 auto = -1 if defer else 0        # -1: chosen by the launcher, workspace zero on entry (no memset)
-                kind = "wgrad_wino2x6" if x6_w else "wgrad_gemmx6" if g6_w else "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
+                amax_x, amax_dy = ctx.amax_x, None
+                if amax_x is not None and (x6_w or g6_w) and not bf16 and H3_WGRAD:
+                    amax_dy = _get_amax(dy)
+                h3_w = amax_dy is not None          # fp16 format (conv_wgrad_x6.hip FMT 1): both operands came with their bounds
+                kind = "wgrad_wino2h3" if (h3_w and x6_w) else "wgrad_gemmh3" if h3_w else "wgrad_wino2x6" if x6_w else "wgrad_gemmx6" if g6_w else "wgrad_wino2" if wino2_w else "wgrad_wino" if wino_w else "wgrad"
                 with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                            f"{kind.replace('_', '-')} P={B * Ho * Wo} Co={cop} Ci={cip} ks={ks}"):
                     if bf16 and x6_w and x.dtype == torch.bfloat16:
@@ -913,6 +919,12 @@ class _Conv(torch.autograd.Function):
                     elif bf16 and not (x6_w or g6_w):
                         call("adm_conv_wgrad_bf16a" if x.dtype == torch.bfloat16 else "adm_conv_wgrad_bf16", ptr(x), ptr(dy), ptr(dwp), B, Ho,
                              Wo, cip, cip, cop, cop, ks, int(up), auto)
+                    elif h3_w and x6_w:
+                        call("adm_conv_wgrad_x6_h3", ptr(x), ptr(dy), ptr(dwp), ptr(bws if det else dbp), B, Ho, Wo, cip, cip, cop, cop,
+                             splits if det else auto, int(up), int(det), ptr(amax_x), ptr(amax_dy))
+                    elif h3_w:
+                        call("adm_gemm_wgrad_x6_h3", ptr(x), ptr(dy), ptr(dwp), ptr(bws if det else dbp), B * Ho * Wo, cip, cip, cop, cop,
+                             splits if det else auto, int(det), ptr(amax_x), ptr(amax_dy))
                     elif det and g6_w:
                         call("adm_gemm_wgrad_x6_ws", ptr(x), ptr(dy), ptr(dwp), ptr(bws), B * Ho * Wo, cip, cip, cop, cop, splits)
                     elif g6_w:

@@ -157,6 +157,13 @@ int adm_conv_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp2, float
                             int Cout, int lddy, int splits, int up, hipStream_t stream);
 int adm_gemm_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy,
                             int splits, hipStream_t stream);
+/* ... and on the fp16 format of adm_conv_fwd_wino2d_h3 (two fp16 terms per operand, three products): amax_x / amax_dy = device
+ * floats >= max|x| / max|dy| (written by the kernels that produced the tensors); det != 0 = the _ws contract (dwp = ws, dbias = bws,
+ * splits from the _plan call).  Replaces the same autograd weight gradient (/root/reference/unet/uncond_unet.py:98-110). */
+int adm_conv_wgrad_x6_h3(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
+                         int lddy, int splits, int up, int det, const float* amax_x, const float* amax_dy, hipStream_t stream);
+int adm_gemm_wgrad_x6_h3(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy,
+                         int splits, int det, const float* amax_x, const float* amax_dy, hipStream_t stream);
 /* kernel variant of adm_conv_fwd_wino2d: -1 (default) chosen per launch, 1 wave-specialised (producer / consumer waves), 0 symmetric;
  * returns the old value */
 int adm_wino2d_variant(int ws);

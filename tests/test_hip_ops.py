@@ -583,6 +583,43 @@ def test_conv_h3_forward_vs_torch(ops, monkeypatch, B, cin, cout, H, up):
     close(nchw(y6)[:, :cout], want)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,ks,up,det", [(8, 64, 96, 32, 3, False, False), (4, 192, 192, 16, 3, False, True), (8, 96, 64, 16, 3, True, False),
+                                                    (2, 32, 64, 8, 3, False, False), (128, 384, 384, 4, 3, False, False),
+                                                    (8, 384, 384, 32, 1, False, False), (9, 192, 96, 32, 1, False, True)])
+def test_conv_h3_weight_gradient_vs_torch(ops, monkeypatch, B, cin, cout, H, ks, up, det):
+    """Weight and bias gradients on the fp16 format (conv_wgrad_x6.hip FMT 1: adm_conv_wgrad_x6_h3 / adm_gemm_wgrad_x6_h3) against
+    autograd's on the CPU: 3x3 (plain, fused nearest x2, split over many workgroups, the deterministic workspace mode) and 1x1; the
+    bounds of x and dy are the true maxima times 1 and times 8 (only an upper bound is needed); the launch record proves the format;
+    the error against an fp64 gradient stays at the six-bf16 form's."""
+    monkeypatch.setattr(ops, "WINO_MIN_M", 1)
+    monkeypatch.setattr(ops, "DETERMINISTIC", det)
+    x = fill.hash_tensor((B, cin, H, H), f"hwx{cin}{H}", 1.0)
+    w = fill.hash_tensor((cout, cin, ks, ks), f"hww{cin}{cout}", 1.0 / math.sqrt(cin * ks * ks))
+    b = fill.hash_tensor((cout,), f"hwb{cout}", 0.5)
+    Ho = 2 * H if up else H
+    gy = fill.hash_tensor((B, cout, Ho, Ho), f"hwg{cout}{H}", 3.0)
+    wr, br = w.clone().double().requires_grad_(True), b.clone().double().requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    (F.conv2d(xin.double(), wr, br, padding=ks // 2) * gy.double()).sum().backward()
+    scale = float(F.conv2d(xin.abs().double().transpose(0, 1), gy.abs().double().transpose(0, 1), padding=ks // 2).max())   # max sum |x dy|
+    errs = {}
+    for mode, loose in (("h3", 1.0), ("h3", 8.0), ("x6", 1.0)):
+        monkeypatch.setattr(ops, "H3_WGRAD", mode == "h3")
+        monkeypatch.setattr(ops, "_get_amax", lambda t, loose=loose: _amax(t) * loose)       # dy's bound (in a model: its producer's)
+        wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+        y = ops.conv2d(nhwc(x), wd, bd, up=up, amax=_amax(dev(x)) * loose)
+        monkeypatch.setattr(ops, "PROFILE", [])
+        (y * nhwc(gy)).sum().backward()
+        kinds = [k[0] for k in ops.PROFILE]
+        tag = ("wgrad_wino2" if ks == 3 else "wgrad_gemm") + mode
+        assert kinds.count(tag) == 1, (tag, kinds)
+        close(wd.grad, wr.grad.float())
+        close(bd.grad, br.grad.float())
+        errs[(mode, loose)] = float((wd.grad.double().cpu() - wr.grad).abs().max()) / scale
+    print(f"dW error / max sum|x dy|: three fp16 {errs[('h3', 1.0)]:.3e} (bound x 8: {errs[('h3', 8.0)]:.3e}), six bf16 {errs[('x6', 1.0)]:.3e}")
+    assert errs[("h3", 1.0)] <= max(2.0 * errs[("x6", 1.0)], 2e-7) and errs[("h3", 8.0)] <= max(4.0 * errs[("x6", 1.0)], 4e-7), errs
+
+
 def test_conv_h3_error_vs_fp64(ops, monkeypatch):
     """Accuracy of the three-fp16-product form against an fp64 convolution, next to the six-bf16-product form and the f32 MFMA kernel,
     relative to max sum |a b|: zero-mean data, all-positive data (no cancellation), heavy-tailed activations (log-normal magnitudes over

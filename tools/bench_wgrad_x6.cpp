@@ -10,16 +10,18 @@ static void run(int B, int H, int Cin, int Cout) {
   std::vector<float> hx(nx), hy(ny);
   for (auto& v : hx) v = (rand() / (float)RAND_MAX) * 2 - 1;
   for (auto& v : hy) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.05f;
-  float *x, *dy, *w0, *w1, *b0, *b1;
-  hipMalloc(&x, nx * 4); hipMalloc(&dy, ny * 4); hipMalloc(&w0, nw * 4); hipMalloc(&w1, nw * 4); hipMalloc(&b0, Cout * 4); hipMalloc(&b1, Cout * 4);
+  float *x, *dy, *w0, *w1, *b0, *b1, *am;
+  hipMalloc(&x, nx * 4); hipMalloc(&dy, ny * 4); hipMalloc(&w0, nw * 4); hipMalloc(&w1, nw * 4); hipMalloc(&b0, Cout * 4); hipMalloc(&b1, Cout * 4); hipMalloc(&am, 8);
+  { const float h[2] = {1.0f, 0.05f}; hipMemcpy(am, h, 8, hipMemcpyHostToDevice); }        // bounds of |x| and |dy|
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(dy, hy.data(), ny * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  float ms[2];
-  for (int which = 0; which < 2; ++which) {
+  float ms[3];
+  for (int which = 0; which < 3; ++which) {
     float* w = which ? w1 : w0; float* b = which ? b1 : b0;
     auto call = [&]() {
       hipMemsetAsync(b, 0, Cout * 4, 0);
-      return which ? adm_conv_wgrad_x6(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0)
+      return which == 2 ? adm_conv_wgrad_x6_h3(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0, 0, am, am + 1, 0)
+           : which ? adm_conv_wgrad_x6(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0)
                    : adm_conv_wgrad_wino2d(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0);
     };
     int rc = 0;
@@ -39,8 +41,8 @@ static void run(int B, int H, int Cin, int Cout) {
   for (size_t i = 0; i < nw; ++i) { mx = fmax(mx, fabs((double)a[i] - c[i])); sc = fmax(sc, fabs((double)a[i])); }
   for (int i = 0; i < Cout; ++i) { bm = fmax(bm, fabs((double)ba[i] - bc[i])); bs = fmax(bs, fabs((double)ba[i])); }
   double fl = 2.0 * B * H * H * (double)Cout * 9 * Cin;
-  printf("B=%d H=%d Cin=%d Cout=%d: f32 %.3f ms (%.1f TF alg)  x6 %.3f ms (%.1f TF alg, splits %d)   max|dw diff| %.2e of %.2e   max|db diff| %.2e of %.2e\n",
-         B, H, Cin, Cout, ms[0], fl / ms[0] / 1e9, ms[1], fl / ms[1] / 1e9, adm_conv_wgrad_x6_plan(B, H, H, Cin, Cout), mx, sc, bm, bs);
+  printf("B=%d H=%d Cin=%d Cout=%d: f32 %.3f ms (%.1f TF alg)  x6 %.3f ms (%.1f TF alg)  h3 %.3f ms (%.1f TF alg, splits %d)   max|dw(h3) - dw(f32)| %.2e of %.2e   max|db diff| %.2e of %.2e\n",
+         B, H, Cin, Cout, ms[0], fl / ms[0] / 1e9, ms[1], fl / ms[1] / 1e9, ms[2], fl / ms[2] / 1e9, adm_conv_wgrad_x6_plan(B, H, H, Cin, Cout), mx, sc, bm, bs);
   hipFree(x); hipFree(dy); hipFree(w0); hipFree(w1); hipFree(b0); hipFree(b1);
 }
 int main() {
