@@ -75,11 +75,21 @@ constexpr int X6P_T = 64, X6N = 64, X6K = 16;      // tiles x couts x K step
 //      DMA of a stage: 1.25 -> 1.02 ms on 128 x 32 x 32 x 384 -> 384 (tools/exp_wino2d_h3.hip).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-template <int FMT> struct X6Fmt {
+// NB = 32-cout blocks per workgroup.  2: 64 couts, four consumer waves (512 threads).  4 (the "wide" form, fp16 format only): 128
+// couts, EIGHT consumer waves, two per SIMD, next to the same four producer waves (768 threads, <= 168 registers): one A image
+// (loads from L2, transform, split, LDS stores -- the part of a stage that does not shrink with the format) now feeds twice the
+// MFMAs, and the launch pulls half the activation bytes out of the L2 (every cout tile re-reads the whole input: at Cin = 384 the
+// 64-cout form reads 74 KB per pixel, ~9.5 TB/s over the launch, more than half of what the L2s deliver).
+template <int FMT, int NB = 2> struct X6Fmt {
   static constexpr int TERMS = FMT ? 2 : 3;
+  static constexpr int NT = 32 * NB;                 // couts per workgroup
+  static constexpr int CONS = 2 * NB;                // consumer waves: (2 tile halves) x (NB cout blocks)
+  static constexpr int THREADS = (CONS + 4) * 64;
   static constexpr int A_STAGE = 4 * TERMS * X6P_T * X6K;
-  static constexpr int B_STAGE = 4 * TERMS * X6N * X6K;
-  static constexpr int DMA_PER_WAVE = 2 * TERMS;     // 4 ex x TERMS images x two 32-row halves / 4 consumer waves
+  static constexpr int B_STAGE = 4 * TERMS * NT * X6K;
+  static constexpr int DMA_PER_WAVE = 2 * TERMS;     // 4 ex x TERMS images x NB 32-row blocks / CONS consumer waves
+  static constexpr int RB = NB == 4 ? 3 : 4;         // weight ring depth (LDS: 2 x 16 + 3 x 32 KB wide; 2 x 16 + 4 x 16 KB fp16, 2 x 24 + 4 x 24 KB bf16)
+  static constexpr int PD = NB == 4 ? 3 : 4;         // producer register sets = stages of loads in flight
 };
 // power-of-two scale that puts 4 * amax below the fp16 range (65504): s * amax <= 16000
 __device__ __host__ inline float h3_scale(float amax) {
@@ -88,7 +98,7 @@ __device__ __host__ inline float h3_scale(float amax) {
   frexpf(16000.f / amax, &e);                         // 16000 / amax = m 2^e, m in [0.5, 1)
   return ldexpf(1.f, e - 1);
 }
-constexpr int X6_RA = 2, X6_RB = 4;                // ring depths (weights three stages ahead: a DMA queues behind the producers' loads)
+constexpr int X6_RA = 2;                           // A ring depth (the weights' is X6Fmt::RB: RB - 1 stages ahead, a DMA queues behind the producers' loads)
 
 // LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), NOT for its global loads
 __device__ __forceinline__ void x6_barrier() {
@@ -188,23 +198,18 @@ struct X6Seq {
   }
 };
 
-template <int FMT>
-__global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
-  using F = X6Fmt<FMT>;
+template <int FMT, int NB>
+__global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
+  using F = X6Fmt<FMT, NB>;
   constexpr int TERMS = F::TERMS;
   float sa = 1.f, inv_scale = 1.f;                     // fp16 format: operand scale and the factor that undoes both scales in the epilogue
   if (FMT) { sa = h3_scale(*p.amax_x); inv_scale = 1.f / (sa * p.wscale); }
   extern __shared__ __attribute__((aligned(16))) unsigned short smem6[];
   unsigned short* As = smem6;                          // [X6_RA][4 ex][3 terms][X6P_T][X6K]
-  unsigned short* Bs = smem6 + X6_RA * F::A_STAGE;     // [X6_RB][4 ex][3 terms][X6N][X6K]
+  unsigned short* Bs = smem6 + X6_RA * F::A_STAGE;     // [RB][4 ex][3 terms][X6N][X6K]
   const int tid = threadIdx.x, lane = tid & 63, hw_wid = tid >> 6;
-#ifdef X6_INTERLEAVE_ROLES
-  const bool producer = hw_wid & 1;
-  const int wid = hw_wid >> 1;                         // role-local wave index 0..3
-#else
-  const bool producer = hw_wid >= 4;
-  const int wid = hw_wid & 3;
-#endif
+  const bool producer = hw_wid >= F::CONS;
+  const int wid = producer ? hw_wid - F::CONS : hw_wid;      // role-local wave index
   int bid = blockIdx.x;
   {   // XCD-aware bijective remap, m-fastest inside an n-tile (see conv_igemm.hip)
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   }
   const int tilesM = gridDim.x / p.tilesN;
   const int tm = bid % tilesM, tn = bid / tilesM;
-  const int mt0 = tm * X6P_T, n0 = tn * X6N;
+  const int mt0 = tm * X6P_T, n0 = tn * F::NT;
   constexpr unsigned OOB = 0x80000000u;
 
   const int c_begin = (p.splitk > 1) ? (int)blockIdx.y * p.chunks_per_split : 0;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
       }
       voff_ey = live ? ey : 4;
     };
-    constexpr int D = 4;                              // stages in flight
+    constexpr int D = F::PD;                          // stages in flight
     f32x4 dA[D][4], dB[D][4];
     int set_ey[D];
     auto issue = [&](int d) {                         // next stage of the sequence -> register set d
@@ -294,14 +299,16 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
     for (int d = 0; d < D; ++d) issue(d);
     __builtin_amdgcn_sched_barrier(0);
     // barrier t separates "A(t) written" from compute(t); A(t) lives in slot t & 1; set t % D is refilled with stage t + D
-    for (int t = 0; t < S; t += D) {
+    constexpr int TRIP = (D & 1) ? 2 * D : D;         // stages per trip: static register sets AND static slots
+    for (int t = 0; t < S; t += TRIP) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        if (t + d < S) {                              // (uniform; S is even, a multiple of 4 without the up-sampling)
-          const bool tl = X6_TL && p.ws && blockIdx.x == 0 && tid == 256 && t + d < 48;
-          unsigned long long* TL = reinterpret_cast<unsigned long long*>(p.ws) + 1024 + (t + d) * 4;
+      for (int k = 0; k < TRIP; ++k) {
+        const int d = k % D;
+        if (t + k < S) {                              // (uniform; S is even, a multiple of 4 without the up-sampling)
+          const bool tl = X6_TL && p.ws && blockIdx.x == 0 && tid == F::CONS * 64 && t + k < 48;
+          unsigned long long* TL = reinterpret_cast<unsigned long long*>(p.ws) + 1024 + (t + k) * 4;
           if (tl) TL[0] = __builtin_readcyclecounter();
-          store(d, d & 1);
+          store(d, k & 1);
           __builtin_amdgcn_sched_barrier(0);
           if (tl) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TL[1] = __builtin_readcyclecounter(); }
           issue(d);                                   // stages past the end read nothing (all offsets out of range)
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 
   // ================================================================== consumer waves: weight DMA, MFMA, output transform
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, p.wbytes, 0x00020000);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / NB, wn = wid % NB;
   const int lr = lane & 31, lh = lane >> 5;
   if (p.splitk > 1) {
     p.y = p.ws + (long)blockIdx.y * ((long)p.Mt * 4) * p.N;
@@ -331,8 +338,8 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
   unsigned b_voff[QW];
 #pragma unroll
   for (int i = 0; i < QW; ++i) {
-    const int q = wid * QW + i, pt = q >> 1;
-    const int row = (q & 1) * 32 + (lane >> 1);
+    const int q = wid * QW + i, pt = q / NB;          // image (ex, term) and 32-row block q % NB of it
+    const int row = (q % NB) * 32 + (lane >> 1);
     const int n = n0 + row;
     const int half = (lane ^ (row >> 3)) & 1;           // logical half stored at physical half (lane & 1)
     b_voff[i] = (n < p.wrows) ? (unsigned)((((long)pt * p.wrows + n) * 16 + half * 8) * 2) : OOB;
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (x6_lds_void*)(dst + i * 512), 16, (int)b_voff[i], kb, 0, 0);
     }
     lb.next(chunks);
-    if (++ld_slot == X6_RB) ld_slot = 0;
+    if (++ld_slot == F::RB) ld_slot = 0;
   };
 
   f32x16 acc[4];
@@ -365,29 +372,28 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
 
   X6Seq cs; cs.init(chunks, p.up);
   int slot_b = 0;
-  issue_b();
-  issue_b();
-  issue_b();
+#pragma unroll
+  for (int i = 0; i < F::RB - 1; ++i) issue_b();
   for (int t = 0; t < S; ++t) {
     const bool tl = X6_TL && p.ws && blockIdx.x == 0 && tid == 0 && t < 48;
     unsigned long long* TL = reinterpret_cast<unsigned long long*>(p.ws) + t * 4;
     if (tl) TL[0] = __builtin_readcyclecounter();
     // B(t) was issued three stages ago; B(t+1) and B(t+2) (six instructions each) may still be in flight.  Plain s_barrier +
     // explicit counters: a release fence would drain the weight prefetch (vmcnt(0)).
-    if (t + 2 < S) { if (FMT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    if (F::RB == 4 && t + 2 < S) { if (FMT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
     else if (t + 1 < S) { if (FMT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (tl) TL[1] = __builtin_readcyclecounter();
-    if (t + 3 < S) issue_b();
+    if (t + F::RB - 1 < S) issue_b();
     const unsigned short* Ab = As + (t & 1) * F::A_STAGE + a_foff;
     const unsigned short* Bb = Bs + slot_b * F::B_STAGE + b_foff;
-    if (++slot_b == X6_RB) slot_b = 0;
+    if (++slot_b == F::RB) slot_b = 0;
     const bool first = cs.cc == 0;                    // first stage of a (block, ey) group: C = 0, no accumulator clearing
     // Fragment reads are issued ONE ex GROUP AHEAD of the MFMAs that use them (two register sets): left to itself the compiler
     // reads a group's six fragments right before its six MFMAs, so every group starts with an exposed LDS round trip (~130 cycles,
     // four times per stage) -- a read returns while the matrix pipe works only if it was issued before the chain it follows
     // (tools/overlap_probe2.hip: ds_read_b128 interleaved with MFMAs of the same wave costs ~6 cycles each, not a latency).
-    u32x4 fa[2][TERMS], fb[2][TERMS];            // 8 bf16 / fp16 values per fragment
+    u32x4 fa[NB == 4 ? 1 : 2][TERMS], fb[NB == 4 ? 1 : 2][TERMS];            // 8 bf16 / fp16 values per fragment
     auto frag = [&](int xi, int set) {
 #pragma unroll
       for (int k = 0; k < TERMS; ++k) {
@@ -397,10 +403,28 @@ __global__ __launch_bounds__(512) void wino2d_x6_kernel(X6P p) {
           continue;
         }
         fa[set][k] = *reinterpret_cast<const u32x4*>(Ab + (xi * TERMS + k) * X6P_T * X6K);
-        fb[set][k] = *reinterpret_cast<const u32x4*>(Bb + (xi * TERMS + k) * X6N * X6K);
+        fb[set][k] = *reinterpret_cast<const u32x4*>(Bb + (xi * TERMS + k) * F::NT * X6K);
       }
     };
     auto products = [&](auto first_tag) {
+      if (NB == 4) {
+        // two consumer waves per SIMD; ONE fragment set: a second set (the 64-cout form's read-ahead) and a zero vector for the first
+        // stage of a group do not fit next to 64 + 64 accumulator registers in 168 -- written with a read-ahead of the next group
+        // (whole, or only of the fragments that are still live) the compiler spills into the loop: 0.80 -> 1.27 ms
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+          frag(xi, 0);
+          if (X6_ABL & 8) continue;
+          const f16x8 a0 = __builtin_bit_cast(f16x8, fa[0][0]), a1 = __builtin_bit_cast(f16x8, fa[0][1]);
+          const f16x8 b0 = __builtin_bit_cast(f16x8, fb[0][0]), b1 = __builtin_bit_cast(f16x8, fb[0][1]);
+          f32x16 c;
+          if (decltype(first_tag)::value) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a0), "v"(b1));
+          else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[xi], 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+        }
+        return;
+      }
       frag(0, 0);
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) {
@@ -574,6 +598,9 @@ extern "C" int adm_split2_f16(const float* src, void* dst, int rows, int cols, f
 
 // Same contract as adm_conv_fwd_wino2d, with wq6 = adm_split3_bf16 of the adm_pack_weight_wino2d operand (16 planes of
 // wrows x Cin).
+static int g_h3_wide = -1;      // -1: chosen per launch, 0: never, 1: whenever the launch qualifies (fp16 format, no split-K)
+extern "C" int adm_wino2d_h3_wide(int v) { const int old = g_h3_wide; g_h3_wide = v; return old; }
+
 static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws, long ws_floats,
                             int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int up, hipStream_t stream,
                             const float* amax_x = nullptr, float wscale = 0.f) {
@@ -591,6 +618,7 @@ static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, 
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin; p.up = up ? 1 : 0;
   p.amax_x = amax_x; p.wscale = wscale;
   p.tilesN = adm_cdiv(N, X6N);
+  const long mtiles = adm_cdiv(Mt, X6P_T);
   p.splitk = 1; p.chunks_per_split = 0; p.ws = X6_TL ? ws : nullptr;
   const long yb = (long)B * H * W * ldy * 4, rb = res ? (long)B * H * W * ldr * 4 : 0;
   p.ybytes = (yb < (1L << 31) && rb < (1L << 31)) ? (int)yb : 0;
@@ -602,18 +630,33 @@ static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, 
     p.splitk = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     p.ws = ws;
   }
-  constexpr int smem0 = (X6_RA * X6Fmt<0>::A_STAGE + X6_RB * X6Fmt<0>::B_STAGE) * (int)sizeof(unsigned short);
-  constexpr int smem1 = (X6_RA * X6Fmt<1>::A_STAGE + X6_RB * X6Fmt<1>::B_STAGE) * (int)sizeof(unsigned short);
+  constexpr int smem0 = (X6_RA * X6Fmt<0>::A_STAGE + X6Fmt<0>::RB * X6Fmt<0>::B_STAGE) * (int)sizeof(unsigned short);
+  constexpr int smem1 = (X6_RA * X6Fmt<1>::A_STAGE + X6Fmt<1>::RB * X6Fmt<1>::B_STAGE) * (int)sizeof(unsigned short);
+  constexpr int smemw = (X6_RA * X6Fmt<1, 4>::A_STAGE + X6Fmt<1, 4>::RB * X6Fmt<1, 4>::B_STAGE) * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smemw) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
-  const long grid = (long)adm_cdiv(Mt, X6P_T) * p.tilesN;
-  if (h3) hipLaunchKernelGGL(wino2d_x6_kernel<1>, dim3((unsigned)grid, p.splitk), dim3(512), smem1, stream, p);
-  else hipLaunchKernelGGL(wino2d_x6_kernel<0>, dim3((unsigned)grid, p.splitk), dim3(512), smem0, stream, p);
+  // wide form (128 couts per workgroup).  What a CU fetches per stage bounds both forms (32 KB of activations + 16 / 32 KB of weights
+  // for 64 / 128 couts: 24 B/clk at the measured stage times, against the ~30 B/clk a CU gets out of its L2), so the wide form wins
+  // where it halves the passes over the activations without wasting MFMAs on padding couts and still fills the chip
+  // (tools/bench_wino2d_x6.cpp, B = 128: 32x32 384->384 0.91 -> 0.71..0.80 ms, 192->576 0.75 -> 0.60, 576->192 0.72 -> 0.66,
+  // 16x16 768->384 0.47 -> 0.41; 192->192 0.27 -> 0.29 and the 8x8 maps 0.086 -> 0.108 lose)
+  bool wide = false;
+  if (h3 && p.splitk == 1 && g_h3_wide != 0 && N > X6N)
+    wide = g_h3_wide == 1 || (mtiles >= 128 && (N >= 256 || Cin >= 384));
+  if (wide) {
+    p.tilesN = adm_cdiv(N, X6Fmt<1, 4>::NT);
+    hipLaunchKernelGGL((wino2d_x6_kernel<1, 4>), dim3((unsigned)(mtiles * p.tilesN), 1), dim3(X6Fmt<1, 4>::THREADS), smemw, stream, p);
+  } else if (h3) {
+    hipLaunchKernelGGL((wino2d_x6_kernel<1, 2>), dim3((unsigned)(mtiles * p.tilesN), p.splitk), dim3(512), smem1, stream, p);
+  } else {
+    hipLaunchKernelGGL((wino2d_x6_kernel<0, 2>), dim3((unsigned)(mtiles * p.tilesN), p.splitk), dim3(512), smem0, stream, p);
+  }
   ADM_CHECK_LAUNCH();
   if (p.splitk > 1) return adm_splitk_reduce(ws, bias, res, y, Mt * 4, N, ldy, ldr, p.splitk, stream);
   return ADM_OK;

@@ -31,13 +31,31 @@ static void run(int B, int H, int Cin, int N, bool check) {
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   double fl = 2.0 * B * H * H * (double)N * 9 * Cin;
   printf("x6 split=%d ABL=%d B=%d H=%d Cin=%d N=%d: %.3f ms  %.1f TFLOP/s algorithmic", wsn ? (int)(wsn / ny) : 1, X6_ABL, B, H, Cin, N, ms, fl / ms / 1e9);
-  if (check) {
-    adm_conv_fwd_wino2d(x, w, nullptr, nullptr, y2, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
-    std::vector<float> a(ny), b(ny);
-    hipMemcpy(a.data(), y, ny * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), y2, ny * 4, hipMemcpyDeviceToHost);
-    double mx = 0, sc = 0;
-    for (size_t i = 0; i < ny; ++i) { mx = fmax(mx, fabs((double)a[i] - b[i])); sc = fmax(sc, fabs((double)b[i])); }
-    printf("   max|x6 - f32 kernel| = %.3e (max|y| %.3e)", mx, sc);
+  if (check) adm_conv_fwd_wino2d(x, w, nullptr, nullptr, y2, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
+  {   // fp16 format: 64-cout workgroups, then the wide (128-cout) form
+    void* wh; float* am; int* flag;
+    hipMalloc(&wh, nw * 4); hipMalloc(&am, 4); hipMalloc(&flag, 4); hipMemset(flag, 0, 4);
+    const float one = 1.0f; hipMemcpy(am, &one, 4, hipMemcpyHostToDevice);
+    adm_split2_f16(w, wh, N, Cin, 2048.f, flag, 0);
+    for (int wide = 0; wide < 2; ++wide) {
+      adm_wino2d_h3_wide(wide);
+      for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_h3(x, wh, nullptr, res, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, am, 2048.f, 0, 0);
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      for (int i = 0; i < reps; ++i) adm_conv_fwd_wino2d_h3(x, wh, nullptr, res, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, am, 2048.f, 0, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float m2; hipEventElapsedTime(&m2, e0, e1); m2 /= reps;
+      printf("  | h3%s %.3f ms %.1f TF", wide ? " wide" : "", m2, fl / m2 / 1e9);
+      if (check) {
+        std::vector<float> a(ny), b(ny);
+        hipMemcpy(a.data(), y, ny * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), y2, ny * 4, hipMemcpyDeviceToHost);
+        double mx = 0, sc = 0;
+        for (size_t i = 0; i < ny; ++i) { mx = fmax(mx, fabs((double)a[i] - b[i])); sc = fmax(sc, fabs((double)b[i])); }
+        printf(" (max|diff to f32 kernel| %.2e of %.2e)", mx, sc);
+      }
+    }
+    adm_wino2d_h3_wide(-1);
+    hipFree(wh); hipFree(am); hipFree(flag);
   }
   printf("\n");
 #if X6_TL
@@ -56,9 +74,13 @@ int main() {
   run(128, 32, 384, 384, false);
   return 0;
 #endif
+  if (getenv("X6_ONLY")) { run(128, 32, 384, 384, false); return 0; }
   run(2, 8, 32, 64, true);
+  run(3, 8, 64, 160, true);
   run(128, 32, 384, 384, true);
   run(128, 32, 192, 192, true);
+  run(128, 32, 576, 192, false);
+  run(128, 32, 192, 576, false);
   run(128, 16, 384, 384, false);
   run(128, 16, 768, 384, false);
   run(128, 8, 384, 384, true);
