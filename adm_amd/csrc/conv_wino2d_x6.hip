@@ -88,8 +88,8 @@ template <int FMT, int NB = 2> struct X6Fmt {
   static constexpr int A_STAGE = 4 * TERMS * X6P_T * X6K;
   static constexpr int B_STAGE = 4 * TERMS * NT * X6K;
   static constexpr int DMA_PER_WAVE = 2 * TERMS;     // 4 ex x TERMS images x NB 32-row blocks / CONS consumer waves
-  static constexpr int RB = NB == 4 ? 3 : 4;         // weight ring depth (LDS: 2 x 16 + 3 x 32 KB wide; 2 x 16 + 4 x 16 KB fp16, 2 x 24 + 4 x 24 KB bf16)
-  static constexpr int PD = NB == 4 ? 3 : 4;         // producer register sets = stages of loads in flight
+  static constexpr int RB = NB > 2 ? 3 : 4;         // weight ring depth (LDS: 2 x 16 + 3 x 32 KB wide; 2 x 16 + 4 x 16 KB fp16, 2 x 24 + 4 x 24 KB bf16)
+  static constexpr int PD = NB > 2 ? 3 : 4;         // producer register sets = stages of loads in flight
 };
 // power-of-two scale that puts 4 * amax below the fp16 range (65504): s * amax <= 16000
 __device__ __host__ inline float h3_scale(float amax) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
     // reads a group's six fragments right before its six MFMAs, so every group starts with an exposed LDS round trip (~130 cycles,
     // four times per stage) -- a read returns while the matrix pipe works only if it was issued before the chain it follows
     // (tools/overlap_probe2.hip: ds_read_b128 interleaved with MFMAs of the same wave costs ~6 cycles each, not a latency).
-    u32x4 fa[NB == 4 ? 1 : 2][TERMS], fb[NB == 4 ? 1 : 2][TERMS];            // 8 bf16 / fp16 values per fragment
+    u32x4 fa[NB > 2 ? 1 : 2][TERMS], fb[NB > 2 ? 1 : 2][TERMS];            // 8 bf16 / fp16 values per fragment
     auto frag = [&](int xi, int set) {
 #pragma unroll
       for (int k = 0; k < TERMS; ++k) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
       }
     };
     auto products = [&](auto first_tag) {
-      if (NB == 4) {
+      if (NB > 2) {
         // two consumer waves per SIMD; ONE fragment set: a second set (the 64-cout form's read-ahead) and a zero vector for the first
         // stage of a group do not fit next to 64 + 64 accumulator registers in 168 -- written with a read-ahead of the next group
         // (whole, or only of the fragments that are still live) the compiler spills into the loop: 0.80 -> 1.27 ms
@@ -633,23 +633,40 @@ static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, 
   constexpr int smem0 = (X6_RA * X6Fmt<0>::A_STAGE + X6Fmt<0>::RB * X6Fmt<0>::B_STAGE) * (int)sizeof(unsigned short);
   constexpr int smem1 = (X6_RA * X6Fmt<1>::A_STAGE + X6Fmt<1>::RB * X6Fmt<1>::B_STAGE) * (int)sizeof(unsigned short);
   constexpr int smemw = (X6_RA * X6Fmt<1, 4>::A_STAGE + X6Fmt<1, 4>::RB * X6Fmt<1, 4>::B_STAGE) * (int)sizeof(unsigned short);
+  constexpr int smem3 = (X6_RA * X6Fmt<1, 3>::A_STAGE + X6Fmt<1, 3>::RB * X6Fmt<1, 3>::B_STAGE) * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smemw) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smemw) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino2d_x6_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
-  // wide form (128 couts per workgroup).  What a CU fetches per stage bounds both forms (32 KB of activations + 16 / 32 KB of weights
-  // for 64 / 128 couts: 24 B/clk at the measured stage times, against the ~30 B/clk a CU gets out of its L2), so the wide form wins
-  // where it halves the passes over the activations without wasting MFMAs on padding couts and still fills the chip
-  // (tools/bench_wino2d_x6.cpp, B = 128: 32x32 384->384 0.91 -> 0.71..0.80 ms, 192->576 0.75 -> 0.60, 576->192 0.72 -> 0.66,
-  // 16x16 768->384 0.47 -> 0.41; 192->192 0.27 -> 0.29 and the 8x8 maps 0.086 -> 0.108 lose)
-  bool wide = false;
-  if (h3 && p.splitk == 1 && g_h3_wide != 0 && N > X6N)
-    wide = g_h3_wide == 1 || (mtiles >= 128 && (N >= 256 || Cin >= 384));
-  if (wide) {
+  // 64, 96 or 128 couts per workgroup (four, six, eight consumer waves).  What a CU fetches per stage bounds all three forms: 32 KB of
+  // activations + 16 / 24 / 32 KB of weights, 24 B/clk at the measured stage times against the ~30 B/clk a CU gets out of its L2; one
+  // workgroup per CU, so a launch takes (rounds of 256 workgroups) x (bytes per stage) -- the 96 form priced a little above its bytes
+  // (its six consumer waves load two SIMDs more than the others).  This model orders every shape of tools/bench_wino2d_x6.cpp
+  // correctly (B = 128, ms for 64 / 96 / 128 couts: 32x32 384->384 0.91 / 0.90 / 0.81, 192->192 0.27 / 0.26 / 0.29, 576->192
+  // 0.72 / 0.60 / 0.65, 192->576 0.75 / 0.63 / 0.59; 16x16 384->384 0.26 / 0.20 / 0.22; 8x8 384->384 0.083 / 0.100 / 0.108).
+  int form = 2;
+  if (h3 && p.splitk == 1 && g_h3_wide != 0 && N > X6N) {
+    if (g_h3_wide == 1) form = 4;
+    else if (g_h3_wide == 3) form = 3;
+    else {
+      const long cost[3] = {48, 60, 64};
+      long best = -1;
+      for (int nb = 2; nb <= 4; ++nb) {
+        const long t = (mtiles * adm_cdiv(N, 32 * nb) + 255) / 256 * cost[nb - 2];
+        if (best < 0 || t < best) { best = t; form = nb; }
+      }
+    }
+  }
+  const bool three = form == 3, wide = form == 4;
+  if (three) {
+    p.tilesN = adm_cdiv(N, X6Fmt<1, 3>::NT);
+    hipLaunchKernelGGL((wino2d_x6_kernel<1, 3>), dim3((unsigned)(mtiles * p.tilesN), 1), dim3(X6Fmt<1, 3>::THREADS), smem3, stream, p);
+  } else if (wide) {
     p.tilesN = adm_cdiv(N, X6Fmt<1, 4>::NT);
     hipLaunchKernelGGL((wino2d_x6_kernel<1, 4>), dim3((unsigned)(mtiles * p.tilesN), 1), dim3(X6Fmt<1, 4>::THREADS), smemw, stream, p);
   } else if (h3) {

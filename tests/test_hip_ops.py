@@ -557,14 +557,14 @@ def _amax(t):
 
 @pytest.mark.parametrize("B,cin,cout,H,up", [(8, 64, 96, 32, False), (4, 192, 192, 16, False), (8, 96, 64, 16, True), (2, 32, 64, 8, False),
                                              (128, 384, 384, 4, False), (4, 64, 160, 8, True), (32, 64, 256, 32, False)])
-@pytest.mark.parametrize("wide", [-1, 1])
+@pytest.mark.parametrize("wide", [-1, 1, 3])
 def test_conv_h3_forward_vs_torch(ops, monkeypatch, request, B, cin, cout, H, up, wide):
     """The 3x3 forward on THREE fp16 products per f32 product (adm_conv_fwd_wino2d_h3) against F.conv2d: plain, with the fused nearest
     x2, with bias and residual, on the split-K shapes of the 4x4 maps -- and with a LOOSE bound (8 x the true maximum: the bound only
     has to be an upper bound).  The launch record proves the format."""
     monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     from adm_amd import hip as _hip
-    old_wide = _hip.lib().adm_wino2d_h3_wide(wide)     # 1: the 128-cout workgroups (eight consumer waves) on every shape; -1: per launch
+    old_wide = _hip.lib().adm_wino2d_h3_wide(wide)     # 1 / 3: the 128- / 96-cout workgroups (eight / six consumer waves) on every shape; -1: per launch
     request.addfinalizer(lambda: _hip.lib().adm_wino2d_h3_wide(old_wide))
     x = fill.hash_tensor((B, cin, H, H), f"h3x{cin}{H}", 1.0)
     w = fill.hash_tensor((cout, cin, 3, 3), f"h3w{cin}{cout}", 1.0 / math.sqrt(cin * 9))

@@ -37,7 +37,7 @@ static void run(int B, int H, int Cin, int N, bool check) {
     hipMalloc(&wh, nw * 4); hipMalloc(&am, 4); hipMalloc(&flag, 4); hipMemset(flag, 0, 4);
     const float one = 1.0f; hipMemcpy(am, &one, 4, hipMemcpyHostToDevice);
     adm_split2_f16(w, wh, N, Cin, 2048.f, flag, 0);
-    for (int wide = 0; wide < 2; ++wide) {
+    for (int wide : {0, 1, 3}) {
       adm_wino2d_h3_wide(wide);
       for (int i = 0; i < 3; ++i) adm_conv_fwd_wino2d_h3(x, wh, nullptr, res, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, am, 2048.f, 0, 0);
       hipDeviceSynchronize();
@@ -45,7 +45,7 @@ static void run(int B, int H, int Cin, int N, bool check) {
       for (int i = 0; i < reps; ++i) adm_conv_fwd_wino2d_h3(x, wh, nullptr, res, y, ws, wsn, B, H, H, Cin, Cin, N, N, N, N, am, 2048.f, 0, 0);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float m2; hipEventElapsedTime(&m2, e0, e1); m2 /= reps;
-      printf("  | h3%s %.3f ms %.1f TF", wide ? " wide" : "", m2, fl / m2 / 1e9);
+      printf("  | h3%s %.3f ms %.1f TF", wide == 1 ? " 128" : wide == 3 ? " 96" : " 64", m2, fl / m2 / 1e9);
       if (check) {
         std::vector<float> a(ny), b(ny);
         hipMemcpy(a.data(), y, ny * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), y2, ny * 4, hipMemcpyDeviceToHost);
@@ -80,6 +80,7 @@ int main() {
   run(128, 32, 384, 384, true);
   run(128, 32, 192, 192, true);
   run(128, 32, 576, 192, false);
+  run(128, 32, 384, 192, false);
   run(128, 32, 192, 576, false);
   run(128, 16, 384, 384, false);
   run(128, 16, 768, 384, false);
