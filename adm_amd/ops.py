@@ -159,22 +159,24 @@ def _h3_flag_tensor(like):
     return _h3_flag
 
 
-def _h3_operands(weight: torch.Tensor, ent: "_Packed"):
-    """fp16-format images of the 2-D Winograd operands (built on first use from the f32 planes; afterwards refreshed by repack_all()
-    with the rest).  Returns (forward image, data-gradient image)."""
+def _h3_operands(weight: torch.Tensor, ent: "_Packed", which: int):
+    """fp16-format image of a 2-D Winograd operand (which = 0: forward, 1: data gradient), built on first use from the f32 planes and
+    afterwards refreshed by repack_all() with the rest.  Only the direction that is asked for is built and kept current: most layers
+    never need the other format's image of the same direction (a third of the repack table's bytes)."""
     global _pack_table
-    if ent.w2fh is None:
+    name = "w2bh" if which else "w2fh"
+    if getattr(ent, name) is None:
         co, ci = weight.shape[0], weight.shape[1]
         cop, cip = ceil32(co), ceil32(ci)
         w = _chk(weight.detach(), "weight")
         w2f, w2b = _new((16, cop, cip), w), _new((16, cip, cop), w)
         call("adm_pack_weight_wino2d", ptr(w), ptr(w2f), ptr(w2b), co, ci, cop, cip)
-        ent.w2fh = torch.empty((16, 2, cop, cip), device=w.device, dtype=torch.float16)
-        ent.w2bh = torch.empty((16, 2, cip, cop), device=w.device, dtype=torch.float16)
-        call("adm_split2_f16", ptr(w2f), ptr(ent.w2fh), cop, cip, H3_WSCALE, ptr(_h3_flag_tensor(w)))
-        call("adm_split2_f16", ptr(w2b), ptr(ent.w2bh), cip, cop, H3_WSCALE, ptr(_h3_flag_tensor(w)))
-        _pack_table = None           # the one-launch repack table must learn the new destinations
-    return ent.w2fh, ent.w2bh
+        rows, cols = (cip, cop) if which else (cop, cip)
+        img = torch.empty((16, 2, rows, cols), device=w.device, dtype=torch.float16)
+        call("adm_split2_f16", ptr(w2b if which else w2f), ptr(img), rows, cols, H3_WSCALE, ptr(_h3_flag_tensor(w)))
+        setattr(ent, name, img)
+        _pack_table = None           # the one-launch repack table must learn the new destination
+    return getattr(ent, name)
 
 
 # ADM_DETERMINISTIC=1: bitwise reproducible backward.  The weight / bias gradient kernels normally combine their pixel-range
@@ -252,28 +254,40 @@ def _wino_operands(weight: torch.Tensor, ent: "_Packed"):
     return ent.wf, ent.wb
 
 
-def _wino2_operands(weight: torch.Tensor, ent: "_Packed"):
-    """2-D Winograd operands (G g G^T, 16 planes) of a packed 3x3 entry, built on first use; refreshed by repack_all().
-    With BF16X6 only their three-term bf16 splits are kept (and returned: conv_wino2d_x6.hip reads nothing else) -- the f32 planes
-    would be rewritten by every repack without ever being read (a third of the repack table's bytes)."""
+def _wino2_operands(weight: torch.Tensor, ent: "_Packed", which: int):
+    """2-D Winograd operand (G g G^T, 16 planes) of a packed 3x3 entry for the forward (which = 0) or the data gradient (1), built on
+    first use; refreshed by repack_all().  With BF16X6 only the three-term bf16 split of the direction that is asked for is built
+    and kept (conv_wino2d_x6.hip reads nothing else): the f32 planes, and the image of a direction that runs on the fp16 format,
+    would be rewritten by every repack without ever being read."""
     global _pack_table
-    if ent.w2f is None and not (BF16X6 and ent.w2f6 is not None):
-        co, ci = weight.shape[0], weight.shape[1]
-        cop, cip = ceil32(co), ceil32(ci)
-        w = _chk(weight.detach(), "weight")
-        ent.w2f = _new((16, cop, cip), w)
-        ent.w2b = _new((16, cip, cop), w)
-        call("adm_pack_weight_wino2d", ptr(w), ptr(ent.w2f), ptr(ent.w2b), co, ci, cop, cip)
-        _pack_table = None
     if not BF16X6:
-        return ent.w2f, ent.w2b
-    if ent.w2f6 is None:
-        _split_x6(ent)
-        _pack_table = None           # the one-launch repack table must learn the new destinations
-    if ent.w2f is not None:          # (just used as the split's source, or left from a run with BF16X6 off)
+        if ent.w2f is None:
+            co, ci = weight.shape[0], weight.shape[1]
+            cop, cip = ceil32(co), ceil32(ci)
+            w = _chk(weight.detach(), "weight")
+            ent.w2f = _new((16, cop, cip), w)
+            ent.w2b = _new((16, cip, cop), w)
+            call("adm_pack_weight_wino2d", ptr(w), ptr(ent.w2f), ptr(ent.w2b), co, ci, cop, cip)
+            _pack_table = None
+        return ent.w2b if which else ent.w2f
+    name = "w2b6" if which else "w2f6"
+    if getattr(ent, name) is None:
+        planes = (ent.w2f, ent.w2b)
+        if planes[0] is None:
+            co, ci = weight.shape[0], weight.shape[1]
+            cop, cip = ceil32(co), ceil32(ci)
+            w = _chk(weight.detach(), "weight")
+            planes = (_new((16, cop, cip), w), _new((16, cip, cop), w))
+            call("adm_pack_weight_wino2d", ptr(w), ptr(planes[0]), ptr(planes[1]), co, ci, cop, cip)
+        src = planes[which]
+        img = torch.empty((16, 3) + tuple(src.shape[1:]), device=src.device, dtype=torch.bfloat16)
+        call("adm_split3_bf16", ptr(src), ptr(img), src.shape[1], src.shape[2])     # K-chunk-tiled: a = a0 + a1 + a2 exactly
+        setattr(ent, name, img)
+        _pack_table = None           # the one-launch repack table must learn the new destination
+    if ent.w2f is not None:          # (left from a run with BF16X6 off)
         ent.w2f = ent.w2b = None
         _pack_table = None
-    return ent.w2f6, ent.w2b6
+    return getattr(ent, name)
 
 
 GEMM_X6_MIN_M = 8192
@@ -303,16 +317,6 @@ def _gemm_x6_operands(ent: "_Packed"):
 def _resplit_gemm_x6(ent: "_Packed"):
     for src, dst in ((ent.fwd, ent.g6f), (ent.bwd, ent.g6b)):
         call("adm_split3_rows", ptr(src), ptr(dst), src.shape[0], src.shape[1], src.shape[1])
-
-
-def _split_x6(ent: "_Packed"):
-    """bf16 images of the 2-D Winograd operands (K-chunk-tiled, see adm_split3_bf16): the exact three-term split a = a0 + a1 + a2."""
-    for src, name in ((ent.w2f, "w2f6"), (ent.w2b, "w2b6")):
-        dst = getattr(ent, name)
-        if dst is None:
-            dst = torch.empty((16, 3) + tuple(src.shape[1:]), device=src.device, dtype=torch.bfloat16)
-            setattr(ent, name, dst)
-        call("adm_split3_bf16", ptr(src), ptr(dst), src.shape[1], src.shape[2])
 
 
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
@@ -803,17 +807,18 @@ class _Conv(torch.autograd.Function):
         if x16 is not None and not use_bf16:
             raise RuntimeError("a bf16-stored activation reached a conv that does not run in the bf16 mode")
         wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, up, tile) and not qkv
-        wq2 = _wino2_operands(weight, pk)[0] if (wino and _use_wino2d(B, Ho, Wo, ks, up, tile)) else None
-        wq = _wino_operands(weight, pk)[0] if (wino and wq2 is None) else None
+        wino2 = wino and _use_wino2d(B, Ho, Wo, ks, up, tile)
+        h3 = wino2 and BF16X6 and FP16X3 and amax is not None       # fp16 format: the operand came with its max |x|
+        wq2 = _wino2_operands(weight, pk, 0) if (wino2 and not h3) else None
+        wq = _wino_operands(weight, pk)[0] if (wino and not wino2) else None
         g6 = not use_bf16 and _use_gemm_x6(_sel_batch(B) * Ho * Wo, ks, up, cop, cip)
-        h3 = wq2 is not None and BF16X6 and FP16X3 and amax is not None       # fp16 format: the operand came with its max |x|
-        kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
+        kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wino2 else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
         with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                    f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
             if h3:
                 sk = 1 if _SELECT_BATCH is not None else hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cip, cop)
                 wsk = _new((sk * B * Ho * Wo * cop,), x) if sk > 1 else None
-                call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk)[0]), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
+                call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk, 0)), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
                      0 if wsk is None else wsk.numel(), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up))
             elif g6:
                 call("adm_gemm_x6", ptr(x), ptr(_gemm_x6_operands(pk)[0]), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
@@ -823,7 +828,7 @@ class _Conv(torch.autograd.Function):
                      ptr(_bf16_operand(pk, "fwd")), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ks, int(up), -1)
             else:
                 _conv_f32(x, pk.fwd, pk.bias, res, y, B, Ho, Wo, cip, cop, ks, int(up), tile, wq, wq2,
-                          pk.w2f6 if (BF16X6 and wq2 is not None) else None)
+                          wq2 if (BF16X6 and wq2 is not None) else None)
         ctx.save_for_backward(x16 if x16 is not None else x, weight, bias)      # (the carrier is not kept)
         _mark_uses(ctx, (1, weight), (2, bias))
         ctx.meta = (ks, up, qkv, residual is not None, bf16)
@@ -996,18 +1001,19 @@ class _Conv(torch.autograd.Function):
             dxf = _new((B, Ho, Wo, cip), dy)
             use_bf16 = bf16 and cop % 64 == 0
             wino = not use_bf16 and _use_wino(B, Ho, Wo, ks, False, -1) and not qkv
-            wq2 = _wino2_operands(weight, pk)[1] if (wino and _use_wino2d(B, Ho, Wo, ks, False, -1)) else None
-            wq = _wino_operands(weight, pk)[1] if (wino and wq2 is None) else None
-            g6 = not use_bf16 and _use_gemm_x6(B * Ho * Wo, ks, up, cip, cop)
-            amax_dy = _get_amax(dy) if (wq2 is not None and BF16X6 and FP16X3) else None
+            wino2 = wino and _use_wino2d(B, Ho, Wo, ks, False, -1)
+            amax_dy = _get_amax(dy) if (wino2 and BF16X6 and FP16X3) else None
             h3 = amax_dy is not None
-            kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wq2 is not None else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
+            wq2 = _wino2_operands(weight, pk, 1) if (wino2 and not h3) else None
+            wq = _wino_operands(weight, pk)[1] if (wino and not wino2) else None
+            g6 = not use_bf16 and _use_gemm_x6(B * Ho * Wo, ks, up, cip, cop)
+            kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wino2 else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
             with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                        f"dgrad{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
                 if h3:
                     sk = hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cop, cip)
                     wsk = _new((sk * B * Ho * Wo * cip,), dy) if sk > 1 else None
-                    call("adm_conv_fwd_wino2d_h3", ptr(dy), ptr(_h3_operands(weight, pk)[1]), None, None, ptr(dxf), ptr(wsk),
+                    call("adm_conv_fwd_wino2d_h3", ptr(dy), ptr(_h3_operands(weight, pk, 1)), None, None, ptr(dxf), ptr(wsk),
                          0 if wsk is None else wsk.numel(), B, Ho, Wo, cop, cop, cip, cip, cip, cip, ptr(amax_dy), H3_WSCALE, 0)
                 elif g6:
                     call("adm_gemm_x6", ptr(dy), ptr(_gemm_x6_operands(pk)[1]), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
@@ -1017,7 +1023,7 @@ class _Conv(torch.autograd.Function):
                          cop, cop, cip, cip, cip, cip, ks, 0, -1)
                 else:
                     _conv_f32(dy, pk.bwd, None, None, dxf, B, Ho, Wo, cop, cip, ks, 0, -1, wq, wq2,
-                              pk.w2b6 if (BF16X6 and wq2 is not None) else None)
+                              wq2 if (BF16X6 and wq2 is not None) else None)
             if up:   # gradient of nearest x2 = 2x2 sum
                 dx = _new((B, Ho // 2, Wo // 2, cip), dy)
                 call("adm_resample2x", ptr(dxf), ptr(dx), B, Ho, Wo, cip, 0, 1.0, 0)

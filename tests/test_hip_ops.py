@@ -684,6 +684,7 @@ def test_conv_h3_weights_follow_repack_all(ops, monkeypatch):
     y0 = ops.conv2d(nhwc(x), w, None, amax=am)
     pk = w._adm_packed
     assert pk.w2fh is not None
+    assert pk.w2f6 is None and pk.w2bh is None and pk.w2b6 is None      # only the image that ran is built (and repacked every step)
     with torch.no_grad():
         w.data.mul_(1.5).add_(0.01)
     ops.repack_all()
