@@ -31,6 +31,9 @@
 #include "common.h"
 #include "../../include/adm_hip.h"
 
+#ifndef XW_D
+#define XW_D (CB == 2 ? 2 : 3)      // producer register sets = stages of loads in flight (sixteen waves: 128 registers, two sets)
+#endif
 #ifndef XW_ABL
 #define XW_ABL 0      // diagnostic builds (tools/bench_wgrad_x6.cpp): 1 no global loads, 2 no transform / split / LDS stores, 8 no MFMAs, 16 no fragment reads
 #endif
@@ -142,20 +145,25 @@ __device__ __forceinline__ void lds_barrier() {    // waits for this wave's LDS 
 // images, reads and MFMAs with the four `ex` planes of a stage holding four consecutive 16-pixel chunks (64 pixels per stage, no
 // transforms, gridDim.y = 1); the epilogue adds the four accumulators.
 // XBF: x holds bf16 (the bf16-storage activations of the opt-in bf16 mode): 8-byte loads, widened in the producer
-template <int MODE, bool XBF, int FMT>
-__global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
+// CB = 64-cout blocks per workgroup.  2 (fp16 format only): 128 couts x 64 cins -- the dY side is TWO 64-cout images, produced by the
+// same four waves (second register set: the one the X side uses for its second row), consumed by eight waves (plane x half): sixteen
+// waves, 128 registers.  The X rows a workgroup fetches and transforms then feed twice the MFMAs: like the forward kernel this one
+// runs at the rate a CU gets bytes out of its L2 (48 KB per stage and 64-cout block before, 21 B/clk at the measured stage time).
+template <int MODE, bool XBF, int FMT, int CB>
+__global__ __launch_bounds__((4 * CB + 8) * 64) void wgrad_x6_kernel(WxP p) {
   constexpr int X_IMG = XFmt<FMT>::IMG, TERMS = XFmt<FMT>::TERMS;
+  constexpr int NCONS = 4 * CB;
   float s_x = 1.f, s_dy = 1.f;
   if (FMT) { s_x = xh3_scale(*p.amax_x); s_dy = xh3_scale(*p.amax_dy); }
   extern __shared__ __attribute__((aligned(16))) unsigned short smx[];
-  unsigned short* As = smx;                        // [2][X_IMG]  dY side: rows = tiles, columns = couts
-  unsigned short* Bs = smx + 2 * X_IMG;            // [2][X_IMG]  X side:  rows = tiles, columns = cins
+  unsigned short* As = smx;                        // [CB][2][X_IMG]  dY side: rows = tiles, columns = couts (one image per 64-cout block)
+  unsigned short* Bs = smx + CB * 2 * X_IMG;       // [2][X_IMG]  X side:  rows = tiles, columns = cins
   const int tid = threadIdx.x, lane = tid & 63, hw_wid = tid >> 6;
   // twelve waves, three per SIMD: 0-3 consume, 4-7 produce the dY-side operand, 8-11 the X-side operand.  With both operands on
   // ONE producer group the kernel was producer-bound (ablation: producers alone 0.373 of 0.448 ms, consumers alone 0.183), and a
   // producer wave is latency-bound, not VALU-throughput-bound (its ~200 instructions per stage use 22 % of the SIMD's issue slots)
-  const bool producer = hw_wid >= 4;
-  const int wid = hw_wid & 3;
+  const bool producer = hw_wid >= NCONS;
+  const int wid = producer ? (hw_wid - NCONS) & 3 : hw_wid;      // consumers: plane = wid & 3, 64-cout block = wid >> 2
   // XCD-aware bijective remap: the hardware deals workgroup i to XCD i % 8; the logical order is split-major (z, ey, tile), so the
   // workgroups of one XCD walk ONE pixel range (and its neighbours) together -- all of a range's (cout tile, cin tile, ey)
   // workgroups read the same x and dy rows.  Dealt round-robin, every XCD streamed every range through its own 4 MB L2
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   const int bz = bid / (p.tiles * NEY), brem = bid - bz * (p.tiles * NEY);
   const int by = brem / p.tiles, bx = brem - by * p.tiles;
   const int tn = bx % p.tilesN, tm = bx / p.tilesN;
-  const int co0 = tm * XT, ci0 = tn * XT;
+  const int co0 = tm * XT * CB, ci0 = tn * XT;
   const int ey = by;
   const int pbeg = bz * p.chunk;
   const int pend = min(p.Pp, pbeg + p.chunk);
@@ -192,6 +200,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
     const int tl = wid * 4 + (lane >> 4), quad = lane & 15;       // tile of the stage, channel quad
     const unsigned a_col = (co0 + quad * 4 < p.Cout) ? (unsigned)(co0 + quad * 4) * 4u : OOB;
+    const unsigned a_col1 = (CB == 2 && co0 + XT + quad * 4 < p.Cout) ? (unsigned)(co0 + XT + quad * 4) * 4u : OOB;     // second 64-cout block
     constexpr unsigned XB = XBF ? 2u : 4u;          // bytes per x element
     const unsigned b_col = (ci0 + quad * 4 < p.Cin) ? (unsigned)(ci0 + quad * 4) * XB : OOB;
     const int Wh = p.W >> 1, Hh = p.H >> 1, lwh = p.lw - 1;
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     // y combination of this pass as a + sgn b: dY rows (r0, r0 + r1, r0 - r1, -r1)[ey], X rows (r0 - r2, r1 + r2, -(r2 - r1), r1 - r3)[ey]
     const float sg = x_side ? (ey == 1 ? 1.f : -1.f) : (ey <= 1 ? 1.f : -1.f);
     const f32x2 sgn = {sg, sg};
-    constexpr int D = 3;                           // stages in flight
+    constexpr int D = XW_D;                        // stages in flight
     f32x4 u0[D][4], u1[D][4];                      // dY side: u0 = (r0 px0, r0 px1, r1 px0, r1 px1); X side: u0 / u1 = rows iA / iB
     // four channels of x at a byte offset: f32 = one 16-byte load; bf16 = one 8-byte load kept RAW in two lanes (widening at the load
     // would put a wait right behind it) and widened by wide4() when the set is consumed
@@ -221,8 +230,10 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
         for (int xi = 0; xi < 4; ++xi) {
           const int px = pbeg + s * STEP + xi * XK + tl;
           const bool pv = px < pend && s < KT;
-          if (!x_side) u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)((pv && a_col != OOB) ? (unsigned)px * ystep + a_col : OOB), 0, 0));
-          else u0[d][xi] = ldx4((pv && b_col != OOB) ? (unsigned)px * xstep + b_col : OOB);
+          if (!x_side) {
+            u0[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)((pv && a_col != OOB) ? (unsigned)px * ystep + a_col : OOB), 0, 0));
+            if (CB == 2) u1[d][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)((pv && a_col1 != OOB) ? (unsigned)px * ystep + a_col1 : OOB), 0, 0));
+          } else u0[d][xi] = ldx4((pv && b_col != OOB) ? (unsigned)px * xstep + b_col : OOB);
         }
         return;
       }
@@ -243,6 +254,14 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
         u0[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y0 != OOB ? y0 + ystep : OOB), 0, 0));
         u0[d][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y1, 0, 0));
         u0[d][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(y1 != OOB ? y1 + ystep : OOB), 0, 0));
+        if (CB == 2) {
+          const unsigned yb = (pv && a_col1 != OOB) ? pix * ystep + a_col1 : OOB;
+          const unsigned z0 = (ey != 3) ? yb : OOB, z1 = (ey != 0 && yb != OOB) ? yb + yrow : OOB;
+          u1[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)z0, 0, 0));
+          u1[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(z0 != OOB ? z0 + ystep : OOB), 0, 0));
+          u1[d][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)z1, 0, 0));
+          u1[d][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(z1 != OOB ? z1 + ystep : OOB), 0, 0));
+        }
         return;
       }
       const bool vA = pv && b_col != OOB && (iA != 0 || ty > 0), vB = pv && b_col != OOB && (iB != 3 || ty < Hh - 1);
@@ -263,13 +282,15 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     // the bias gradient = sum of every dY pixel = the ex = 1 component (e0 + e1 along x) of the ey = 1 workgroups (r0 + r1 along y)
     const bool bias_wg = p.dbias != nullptr && tn == 0 && ey == (MODE == 1 ? 0 : 1);     // (workgroup-uniform)
     const bool do_bias = bias_wg && !x_side;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f}, bsum1 = {0.f, 0.f, 0.f, 0.f};
     unsigned short* la = As + tl * XROW + quad * 4;
     unsigned short* lb = Bs + tl * XROW + quad * 4;
     auto store = [&](int d, int slot) {            // y combination, x transforms, split, into slot
       if (XW_ABL & 2) return;
       if (MODE == 1) {
         if (do_bias) bsum = add4x(bsum, add4x(add4x(u0[d][0], u0[d][1]), add4x(u0[d][2], u0[d][3])));
+        if (do_bias && CB == 2) bsum1 = add4x(bsum1, add4x(add4x(u1[d][0], u1[d][1]), add4x(u1[d][2], u1[d][3])));
+        if (!x_side && CB == 2) store_planes<FMT>(u1[d], la + (2 + slot) * X_IMG, s_dy);
         if (x_side && XBF) {
           const f32x4 w[4] = {wide4(u0[d][0]), wide4(u0[d][1]), wide4(u0[d][2]), wide4(u0[d][3])};
           store_planes<FMT>(w, lb + slot * X_IMG, s_x);
@@ -284,6 +305,12 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
         const f32x4 a[4] = {e[0], add4x(e[0], e[1]), sub4x(e[0], e[1]), sub4x(zero, e[1])};
         if (do_bias) bsum = add4x(bsum, a[1]);
         store_planes<FMT>(a, la + slot * X_IMG, s_dy);
+        if (CB == 2) {
+          const f32x4 f[2] = {fma4s(u1[d][0], u1[d][2], sgn), fma4s(u1[d][1], u1[d][3], sgn)};
+          const f32x4 c[4] = {f[0], add4x(f[0], f[1]), sub4x(f[0], f[1]), sub4x(zero, f[1])};
+          if (do_bias) bsum1 = add4x(bsum1, c[1]);
+          store_planes<FMT>(c, la + (2 + slot) * X_IMG, s_dy);
+        }
         return;
       }
       f32x4 dd[4];
@@ -311,23 +338,31 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
     if (bias_wg) {     // lanes l, l + 16, l + 32, l + 48 of a wave hold four tiles of the same channel quad; four dY-side waves
 #pragma unroll
       for (int j = 0; j < 4; ++j) { bsum[j] += __shfl_xor(bsum[j], 16, 64); bsum[j] += __shfl_xor(bsum[j], 32, 64); }
+      if (CB == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bsum1[j] += __shfl_xor(bsum1[j], 16, 64); bsum1[j] += __shfl_xor(bsum1[j], 32, 64); }
+      }
       float* red = reinterpret_cast<float*>(smx);  // every image has been consumed: the consumers are past the last barrier ...
-      lds_barrier();                               // ... once they arrive here (all twelve waves make the same two extra barriers)
+      lds_barrier();                               // ... once they arrive here (all waves make the same two extra barriers)
       if (do_bias && lane < 16) *reinterpret_cast<f32x4*>(red + (wid * 16 + lane) * 4) = bsum;
+      if (do_bias && CB == 2 && lane < 16) *reinterpret_cast<f32x4*>(red + ((4 + wid) * 16 + lane) * 4) = bsum1;
       lds_barrier();
-      if (do_bias && wid == 0 && lane < 16 && a_col != OOB) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(red + lane * 4);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * 16 + lane) * 4);
+      for (int hb = 0; hb < CB; ++hb) {
+        if (do_bias && wid == 0 && lane < 16 && (hb ? a_col1 : a_col) != OOB) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(red + (hb * 64 + lane) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (p.split_stride > 0) p.dbias[(long)bz * p.bias_stride + co0 + quad * 4 + j] = v[j];
-          else atomicAdd(&p.dbias[co0 + quad * 4 + j], v[j]);
+          for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + ((hb * 4 + w) * 16 + lane) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (p.split_stride > 0) p.dbias[(long)bz * p.bias_stride + co0 + hb * XT + quad * 4 + j] = v[j];
+            else atomicAdd(&p.dbias[co0 + hb * XT + quad * 4 + j], v[j]);
+          }
         }
       }
     }
     };
-    if (hw_wid >= 8) produce(std::true_type{});
+    if (hw_wid >= NCONS + 4) produce(std::true_type{});
     else produce(std::false_type{});
     lds_barrier();                                 // the consumers' plane exchange (two barriers for all twelve waves)
     lds_barrier();
@@ -340,7 +375,8 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   // transposed fragment read: 16-lane group g, lane i = 4 q + p of it: row (tile) 8 (g >> 1) + q [+ 4 for the second read],
   // columns 16 (g & 1) + 4 p .. + 3 of a 32-channel block; the lane receives channel 16 (g & 1) + i of those four tiles
   const int g = lane >> 4, gi = lane & 15;
-  const int foff = (8 * (g >> 1) + (gi >> 2)) * XROW + 16 * (g & 1) + 4 * (gi & 3) + wid * TERMS * XK * XROW;
+  const int cpl = wid & 3, chalf = wid >> 2;         // plane (MODE 1: pixel chunk) and 64-cout block of this wave
+  const int foff = (8 * (g >> 1) + (gi >> 2)) * XROW + 16 * (g & 1) + 4 * (gi & 3) + cpl * TERMS * XK * XROW;
   f32x16 tot[2][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -354,7 +390,7 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
   };
   for (int s = 0; s < KT; ++s) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const unsigned short* Ab = As + (s & 1) * X_IMG + foff;
+    const unsigned short* Ab = As + (chalf * 2 + (s & 1)) * X_IMG + foff;
     const unsigned short* Bb = Bs + (s & 1) * X_IMG + foff;
     bf16x8 a[2][TERMS], b[2][TERMS];
 #pragma unroll
@@ -413,17 +449,18 @@ __global__ __launch_bounds__(768) void wgrad_x6_kernel(WxP p) {
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          ex_t[(wid * XT + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XT + nb * 32 + lr] = osgn * tot[mb][nb][r];
+          ex_t[((chalf * 4 + cpl) * XT + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XT + nb * 32 + lr] = osgn * tot[mb][nb][r];
   }
   lds_barrier();
   const int ci = ci0 + lane;                       // wave w: couts 16 w .. 16 w + 15 of the tile, lane = cin (256-byte rows)
   if (ci >= p.Cin) return;
 #pragma unroll 4
   for (int r = 0; r < 16; ++r) {
-    const int cr = wid * 16 + r, co = co0 + cr;
+    const int cr = cpl * 16 + r, co = co0 + chalf * XT + cr;
     if (co >= p.Cout) break;
-    const float t0 = ex_t[(0 * XT + cr) * XT + lane], t1 = ex_t[(1 * XT + cr) * XT + lane];
-    const float t2 = ex_t[(2 * XT + cr) * XT + lane], t3 = ex_t[(3 * XT + cr) * XT + lane];
+    const float* eh = ex_t + chalf * 4 * XT * XT;
+    const float t0 = eh[(0 * XT + cr) * XT + lane], t1 = eh[(1 * XT + cr) * XT + lane];
+    const float t2 = eh[(2 * XT + cr) * XT + lane], t3 = eh[(3 * XT + cr) * XT + lane];
     if (MODE == 1) {
       const float w = (t0 + t1) + (t2 + t3);
       float* dst1 = p.dwp + (long)bz * p.split_stride + (long)co * p.Cin + ci;
@@ -446,25 +483,30 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
                   int lddy, int splits, bool det, bool plan_only, int up, hipStream_t stream, int xbf = 0,
                   const float* amax_x = nullptr, const float* amax_dy = nullptr);
 
+int g_wgrad_cb = -1;      // -1: chosen per launch, 1 / 2: 64-cout blocks per workgroup of the fp16-format kernel (2 where it qualifies)
+// 128 couts per workgroup: fp16 format, not the deterministic workspace mode (its split plan is made without the format), > 64 couts
+inline int wgrad_cb(int fmt, bool det, int Cout) { return (fmt && !det && Cout > XT && g_wgrad_cb != 1) ? 2 : 1; }
+
 template <int MODE>
-int wgrad_x6_launch(const WxP& p, dim3 grid, int xbf, int fmt, hipStream_t stream) {
+int wgrad_x6_launch(const WxP& p, dim3 grid, int xbf, int fmt, int cb, hipStream_t stream) {
   static bool attr_set = false;
   constexpr int smem0 = 4 * XFmt<0>::IMG * (int)sizeof(unsigned short), smem1 = 4 * XFmt<1>::IMG * (int)sizeof(unsigned short);
+  constexpr int smem2 = 6 * XFmt<1>::IMG * (int)sizeof(unsigned short);
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem0) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, false, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6_kernel<MODE, false, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem2) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
-  if (fmt) hipLaunchKernelGGL((wgrad_x6_kernel<MODE, false, 1>), grid, dim3(768), smem1, stream, p);
-  else if (xbf) hipLaunchKernelGGL((wgrad_x6_kernel<MODE, true, 0>), grid, dim3(768), smem0, stream, p);
-  else hipLaunchKernelGGL((wgrad_x6_kernel<MODE, false, 0>), grid, dim3(768), smem0, stream, p);
+  if (fmt && cb == 2) hipLaunchKernelGGL((wgrad_x6_kernel<MODE, false, 1, 2>), grid, dim3(1024), smem2, stream, p);
+  else if (fmt) hipLaunchKernelGGL((wgrad_x6_kernel<MODE, false, 1, 1>), grid, dim3(768), smem1, stream, p);
+  else if (xbf) hipLaunchKernelGGL((wgrad_x6_kernel<MODE, true, 0, 1>), grid, dim3(768), smem0, stream, p);
+  else hipLaunchKernelGGL((wgrad_x6_kernel<MODE, false, 0, 1>), grid, dim3(768), smem0, stream, p);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
-
-// MODE 1 host side: P pixels, no geometry
 int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
                       bool det, bool plan_only, hipStream_t stream, int xbf = 0, const float* amax_x = nullptr,
                       const float* amax_dy = nullptr);
@@ -490,7 +532,8 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   p.Pp = (int)(P / 4); p.H = H; p.W = W; p.lw = lw; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy;
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, XT);
-  const long tiles = (long)adm_cdiv(Cout, XT) * p.tilesN * 4;
+  const int cb = wgrad_cb(fmt, det, Cout);
+  const long tiles = (long)adm_cdiv(Cout, XT * cb) * p.tilesN * 4;
   const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;      // zero-at-rest workspace: no memset
   if (splits <= 0) {
     // one workgroup per CU: 256 slots.  The split count whose workgroup total fills whole rounds best, with a mild preference for
@@ -514,8 +557,8 @@ int wgrad_x6_impl(const float* x, const float* dy, float* dwp, float* dbias, int
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
   if (p.atomic && !prezeroed && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * 12 * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
-  p.tiles = adm_cdiv(Cout, XT) * p.tilesN;
-  return wgrad_x6_launch<0>(p, dim3(p.tiles * 4 * splits), xbf, fmt, stream);
+  p.tiles = adm_cdiv(Cout, XT * cb) * p.tilesN;
+  return wgrad_x6_launch<0>(p, dim3(p.tiles * 4 * splits), xbf, fmt, cb, stream);
 }
 
 int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy, int splits,
@@ -532,7 +575,8 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
   p.Pp = (int)P; p.H = 0; p.W = 0; p.lw = 0; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.up = 0;
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, XT);
-  const long tiles = (long)adm_cdiv(Cout, XT) * p.tilesN;
+  const int cb = wgrad_cb(fmt, det, Cout);
+  const long tiles = (long)adm_cdiv(Cout, XT * cb) * p.tilesN;
   constexpr int STEP = 4 * XK;
   const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;
   if (splits <= 0) {        // whole rounds of 256 workgroups (one per CU); >= 6 stages (384 pixels) per split
@@ -555,8 +599,8 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
   p.bias_stride = det ? Cout : 0;
   p.atomic = splits > 1 && !det;
   if (p.atomic && !prezeroed && hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cout * Cin, stream) != hipSuccess) return ADM_ELAUNCH;
-  p.tiles = adm_cdiv(Cout, XT) * p.tilesN;
-  return wgrad_x6_launch<1>(p, dim3(p.tiles * splits), xbf, fmt, stream);
+  p.tiles = adm_cdiv(Cout, XT * cb) * p.tilesN;
+  return wgrad_x6_launch<1>(p, dim3(p.tiles * splits), xbf, fmt, cb, stream);
 }
 
 }  // namespace
@@ -625,3 +669,7 @@ extern "C" int adm_gemm_wgrad_x6_h3(const float* x, const float* dy, float* dwp,
   if (!amax_x || !amax_dy) return ADM_EINVAL;
   return wgrad_x6_1x1_impl(x, dy, dwp, dbias, P, Cin, ldx, Cout, lddy, splits, det != 0, false, stream, 0, amax_x, amax_dy);
 }
+
+// form of the fp16-format weight-gradient kernels: -1 (default) 128 couts per workgroup where the launch qualifies, 1 always 64, 2 as -1;
+// returns the old value
+extern "C" int adm_wgrad_h3_blocks(int v) { const int old = g_wgrad_cb; g_wgrad_cb = v; return old; }

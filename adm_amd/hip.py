@@ -31,6 +31,7 @@ _SIGS = {
     "adm_wino2d_splitk": [I, I, I, I, I],
     "adm_wino2d_variant": [I],
     "adm_wino2d_h3_wide": [I],
+    "adm_wgrad_h3_blocks": [I],
     "adm_conv_fwd_wino2d_x6": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P],
     "adm_conv_fwd_wino2d_x6_up": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P],
     "adm_wino2d_x6_splitk": [I, I, I, I, I],
@@ -158,6 +159,8 @@ def lib() -> ctypes.CDLL:
             fn.restype = c_long if name in ("adm_aug_workspace_floats", "adm_linattn_ws_floats") else c_int
         if os.environ.get("ADM_H3_WIDE") is not None:      # A/B switch: form of the fp16-format 3x3 kernel (-1 per launch, 0 / 1)
             _lib.adm_wino2d_h3_wide(int(os.environ["ADM_H3_WIDE"]))
+        if os.environ.get("ADM_WGRAD_H3_BLOCKS") is not None:      # A/B switch: 64-cout blocks per workgroup of the fp16-format weight gradient
+            _lib.adm_wgrad_h3_blocks(int(os.environ["ADM_WGRAD_H3_BLOCKS"]))
     return _lib
 
 
@@ -170,7 +173,7 @@ def ptr(t) -> c_void_p:
 
 
 NO_STREAM = ("adm_version", "adm_conv_splitk", "adm_gn_splits", "adm_aug_workspace_floats", "adm_conv_wgrad_plan",
-             "adm_sumsq_blocks", "adm_lnc_blocks", "adm_bn_blocks", "adm_linattn_ws_floats", "adm_wino2d_splitk", "adm_wino2d_x6_splitk", "adm_wino2d_variant", "adm_wino2d_h3_wide", "adm_gn_fused", "adm_conv_wgrad_x6_plan", "adm_gemm_wgrad_x6_plan")      # host-side queries: no stream argument, called as lib().name(...)
+             "adm_sumsq_blocks", "adm_lnc_blocks", "adm_bn_blocks", "adm_linattn_ws_floats", "adm_wino2d_splitk", "adm_wino2d_x6_splitk", "adm_wino2d_variant", "adm_wino2d_h3_wide", "adm_wgrad_h3_blocks", "adm_gn_fused", "adm_conv_wgrad_x6_plan", "adm_gemm_wgrad_x6_plan")      # host-side queries: no stream argument, called as lib().name(...)
 
 
 def call(name: str, *args):

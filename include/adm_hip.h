@@ -170,6 +170,9 @@ int adm_wino2d_variant(int ws);
 /* form of adm_conv_fwd_wino2d_h3's kernel: -1 (default) chosen per launch, 1 the 128-cout workgroups (eight consumer waves) / 3 the 96-cout
  * workgroups (six) wherever the launch qualifies (no split-K), 0 always 64-cout workgroups; returns the old value */
 int adm_wino2d_h3_wide(int v);
+/* form of adm_conv_wgrad_x6_h3 / adm_gemm_wgrad_x6_h3's kernel: -1 (default) / 2: 128 couts per workgroup (sixteen waves) where the launch
+ * qualifies (more than 64 couts, not the deterministic workspace mode), 1: always 64; returns the old value */
+int adm_wgrad_h3_blocks(int v);
 /* split count (>= 1) adm_conv_fwd_wino2d uses when given a workspace of that many B*H*W*N-float slices (small maps) */
 int adm_wino2d_splitk(int B, int H, int W, int Cin, int N);
 

@@ -589,14 +589,19 @@ def test_conv_h3_forward_vs_torch(ops, monkeypatch, request, B, cin, cout, H, up
 
 @pytest.mark.parametrize("B,cin,cout,H,ks,up,det", [(8, 64, 96, 32, 3, False, False), (4, 192, 192, 16, 3, False, True), (8, 96, 64, 16, 3, True, False),
                                                     (2, 32, 64, 8, 3, False, False), (128, 384, 384, 4, 3, False, False),
-                                                    (8, 384, 384, 32, 1, False, False), (9, 192, 96, 32, 1, False, True)])
-def test_conv_h3_weight_gradient_vs_torch(ops, monkeypatch, B, cin, cout, H, ks, up, det):
+                                                    (8, 384, 384, 32, 1, False, False), (9, 192, 96, 32, 1, False, True),
+                                                    (4, 64, 160, 16, 3, True, False), (33, 96, 224, 16, 1, False, False)])
+@pytest.mark.parametrize("blocks", [-1, 1])
+def test_conv_h3_weight_gradient_vs_torch(ops, monkeypatch, request, B, cin, cout, H, ks, up, det, blocks):
     """Weight and bias gradients on the fp16 format (conv_wgrad_x6.hip FMT 1: adm_conv_wgrad_x6_h3 / adm_gemm_wgrad_x6_h3) against
     autograd's on the CPU: 3x3 (plain, fused nearest x2, split over many workgroups, the deterministic workspace mode) and 1x1; the
     bounds of x and dy are the true maxima times 1 and times 8 (only an upper bound is needed); the launch record proves the format;
     the error against an fp64 gradient stays at the six-bf16 form's."""
     monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     monkeypatch.setattr(ops, "DETERMINISTIC", det)
+    from adm_amd import hip as _hip
+    old_blocks = _hip.lib().adm_wgrad_h3_blocks(blocks)      # -1: 128 couts per workgroup (sixteen waves) where > 64 couts; 1: 64
+    request.addfinalizer(lambda: _hip.lib().adm_wgrad_h3_blocks(old_blocks))
     x = fill.hash_tensor((B, cin, H, H), f"hwx{cin}{H}", 1.0)
     w = fill.hash_tensor((cout, cin, ks, ks), f"hww{cin}{cout}", 1.0 / math.sqrt(cin * ks * ks))
     b = fill.hash_tensor((cout,), f"hwb{cout}", 0.5)

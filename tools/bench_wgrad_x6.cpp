@@ -15,12 +15,13 @@ static void run(int B, int H, int Cin, int Cout) {
   { const float h[2] = {1.0f, 0.05f}; hipMemcpy(am, h, 8, hipMemcpyHostToDevice); }        // bounds of |x| and |dy|
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(dy, hy.data(), ny * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  float ms[3];
-  for (int which = 0; which < 3; ++which) {
+  float ms[4];
+  for (int which = 0; which < 4; ++which) {
     float* w = which ? w1 : w0; float* b = which ? b1 : b0;
     auto call = [&]() {
       hipMemsetAsync(b, 0, Cout * 4, 0);
-      return which == 2 ? adm_conv_wgrad_x6_h3(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0, 0, am, am + 1, 0)
+      adm_wgrad_h3_blocks(which == 3 ? 2 : 1);
+      return which >= 2 ? adm_conv_wgrad_x6_h3(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0, 0, am, am + 1, 0)
            : which ? adm_conv_wgrad_x6(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0)
                    : adm_conv_wgrad_wino2d(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0);
     };
@@ -41,8 +42,8 @@ static void run(int B, int H, int Cin, int Cout) {
   for (size_t i = 0; i < nw; ++i) { mx = fmax(mx, fabs((double)a[i] - c[i])); sc = fmax(sc, fabs((double)a[i])); }
   for (int i = 0; i < Cout; ++i) { bm = fmax(bm, fabs((double)ba[i] - bc[i])); bs = fmax(bs, fabs((double)ba[i])); }
   double fl = 2.0 * B * H * H * (double)Cout * 9 * Cin;
-  printf("B=%d H=%d Cin=%d Cout=%d: f32 %.3f ms (%.1f TF alg)  x6 %.3f ms (%.1f TF alg)  h3 %.3f ms (%.1f TF alg, splits %d)   max|dw(h3) - dw(f32)| %.2e of %.2e   max|db diff| %.2e of %.2e\n",
-         B, H, Cin, Cout, ms[0], fl / ms[0] / 1e9, ms[1], fl / ms[1] / 1e9, ms[2], fl / ms[2] / 1e9, adm_conv_wgrad_x6_plan(B, H, H, Cin, Cout), mx, sc, bm, bs);
+  printf("B=%d H=%d Cin=%d Cout=%d: f32 %.3f ms (%.1f TF alg)  x6 %.3f ms (%.1f TF alg)  h3 %.3f ms (%.1f TF alg, splits %d)  h3 128-cout %.3f ms (%.1f TF)   max|dw(h3 128) - dw(f32)| %.2e of %.2e   max|db diff| %.2e of %.2e\n",
+         B, H, Cin, Cout, ms[0], fl / ms[0] / 1e9, ms[1], fl / ms[1] / 1e9, ms[2], fl / ms[2] / 1e9, adm_conv_wgrad_x6_plan(B, H, H, Cin, Cout), ms[3], fl / ms[3] / 1e9, mx, sc, bm, bs);
   hipFree(x); hipFree(dy); hipFree(w0); hipFree(w1); hipFree(b0); hipFree(b1);
 }
 int main() {
@@ -51,8 +52,10 @@ int main() {
 #endif
   run(2, 8, 32, 64);
   run(8, 16, 96, 64);
+  run(4, 16, 96, 160);
   run(128, 32, 192, 192);
   run(128, 32, 384, 192);
+  run(128, 32, 576, 192);
   run(128, 16, 384, 384);
   run(128, 16, 768, 384);
   run(128, 8, 384, 384);
