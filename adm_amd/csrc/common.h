@@ -13,6 +13,26 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "../../include/adm_hip.h"
+#ifdef __HIPCC__
+// bound vectors (ADM_AMAX_SLOTS x ADM_AMAX_STRIDE floats: include/adm_hip.h).  Producer side: the wave's maximum goes to the slot of this
+// wave; consumer side: every lane reads one slot, wave maximum (all lanes return it).
+__device__ __forceinline__ void adm_amax_commit(float am, float* amax) {
+  if (!amax) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+  if ((threadIdx.x & 63) == 0 && am > 0.f) {
+    const unsigned wave = (unsigned)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6) + (unsigned)blockIdx.y * 7u;
+    atomicMax(reinterpret_cast<unsigned*>(amax + (wave % ADM_AMAX_SLOTS) * ADM_AMAX_STRIDE), __float_as_uint(am));
+  }
+}
+__device__ __forceinline__ float adm_amax_read(const float* amax) {
+  float v = amax[((threadIdx.x & 63) % ADM_AMAX_SLOTS) * ADM_AMAX_STRIDE];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif
 
 #define ADM_CHECK_LAUNCH()                                   \
   do {                                                       \

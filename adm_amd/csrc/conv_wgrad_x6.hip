@@ -154,7 +154,7 @@ __global__ __launch_bounds__((4 * CB + 8) * 64) void wgrad_x6_kernel(WxP p) {
   constexpr int X_IMG = XFmt<FMT>::IMG, TERMS = XFmt<FMT>::TERMS;
   constexpr int NCONS = 4 * CB;
   float s_x = 1.f, s_dy = 1.f;
-  if (FMT) { s_x = xh3_scale(*p.amax_x); s_dy = xh3_scale(*p.amax_dy); }
+  if (FMT) { s_x = xh3_scale(adm_amax_read(p.amax_x)); s_dy = xh3_scale(adm_amax_read(p.amax_dy)); }
   extern __shared__ __attribute__((aligned(16))) unsigned short smx[];
   unsigned short* As = smx;                        // [CB][2][X_IMG]  dY side: rows = tiles, columns = couts (one image per 64-cout block)
   unsigned short* Bs = smx + CB * 2 * X_IMG;       // [2][X_IMG]  X side:  rows = tiles, columns = cins

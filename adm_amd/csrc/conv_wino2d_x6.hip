@@ -53,7 +53,7 @@ struct X6P {
   int splitk, chunks_per_split; float* ws;
   int ybytes, rbytes;                  // > 0: y / res fit 32-bit byte offsets (branch-free buffer epilogue)
   int up;                              // 1: x is [B][H/2][W/2][ldx] and the conv runs on its nearest x2 up-sampling (Conv2d(up=True))
-  const float* amax_x; float wscale;   // fp16 format only: device scalar >= max |x|; the weights' (power-of-two) scale
+  const float* amax_x; float wscale;   // fp16 format only: bound vector (adm_hip.h) of |x|; the weights' (power-of-two) scale
 };
 
 typedef __attribute__((address_space(3))) void x6_lds_void;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
   using F = X6Fmt<FMT, NB>;
   constexpr int TERMS = F::TERMS;
   float sa = 1.f, inv_scale = 1.f;                     // fp16 format: operand scale and the factor that undoes both scales in the epilogue
-  if (FMT) { sa = h3_scale(*p.amax_x); inv_scale = 1.f / (sa * p.wscale); }
+  if (FMT) { sa = h3_scale(adm_amax_read(p.amax_x)); inv_scale = 1.f / (sa * p.wscale); }
   extern __shared__ __attribute__((aligned(16))) unsigned short smem6[];
   unsigned short* As = smem6;                          // [X6_RA][4 ex][3 terms][X6P_T][X6K]
   unsigned short* Bs = smem6 + X6_RA * F::A_STAGE;     // [RB][4 ex][3 terms][X6N][X6K]

@@ -126,11 +126,7 @@ __global__ void add3_kernel(const f32x4* __restrict__ a, const f32x4* __restrict
     am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     y[i] = v;
   }
-  if (amax) {                                    // max |y| for a fp16-format conv that consumes the sum (conv_wino2d_x6.hip)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(am));
-  }
+  adm_amax_commit(am, amax);                     // max |y| (a bound vector) for a fp16-format conv that consumes the sum (conv_wino2d_x6.hip)
 }
 __global__ void copy_channels_kernel(const float* __restrict__ src, int lds_, int src_off, float* __restrict__ dst,
                                      int ldd, int dst_off, long M, int C4, float scale, int acc) {

@@ -29,12 +29,7 @@ __device__ __forceinline__ void gn_store4(float* y, long quad_idx, f32x4 u, int 
 __device__ __forceinline__ float gn_amax4(float am, f32x4 u) {
   return fmaxf(fmaxf(am, fmaxf(fabsf(u[0]), fabsf(u[1]))), fmaxf(fabsf(u[2]), fabsf(u[3])));
 }
-__device__ __forceinline__ void gn_amax_commit(float am, float* amax) {
-  if (!amax) return;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-  if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(am));
-}
+__device__ __forceinline__ void gn_amax_commit(float am, float* amax) { adm_amax_commit(am, amax); }      // (a bound vector: common.h)
 
 __host__ __device__ inline int gn_rows_par(int C) { int r = 256 / (C / 4); return r < 1 ? 1 : r; }
 

@@ -106,15 +106,27 @@ _amax_pool, _amax_next = None, 0
 _AMAX_POOL = 4096
 
 
+AMAX_FLOATS = 64 * 32      # a bound vector: ADM_AMAX_SLOTS floats at a stride of ADM_AMAX_STRIDE (include/adm_hip.h)
+
+
 def _amax_slot(like: torch.Tensor) -> torch.Tensor:
-    """A zeroed device float for a kernel to raise to max |output| (atomicMax).  Slots come from a pool that is zero-filled once per
-    4096 slots (no per-call fill launch); a slot lives as long as a tensor refers to it."""
+    """A zeroed BOUND VECTOR (include/adm_hip.h: 64 floats, one cache line apart; the bound is their maximum) for a kernel to raise to
+    max |output| -- every wave raises its own slot: one address for all of them serialised the atomics of a launch (185 us for
+    a 22 us add3).  Vectors come from a pool that is zero-filled once per 4096 vectors (no per-call fill launch); a vector lives as
+    long as a tensor refers to it."""
     global _amax_pool, _amax_next
     if _amax_pool is None or _amax_next >= _AMAX_POOL or _amax_pool.device != like.device:
-        _amax_pool, _amax_next = torch.zeros(_AMAX_POOL, device=like.device, dtype=_f32), 0
-    s = _amax_pool[_amax_next:_amax_next + 1]
+        _amax_pool, _amax_next = torch.zeros(_AMAX_POOL * AMAX_FLOATS, device=like.device, dtype=_f32), 0
+    s = _amax_pool[_amax_next * AMAX_FLOATS:(_amax_next + 1) * AMAX_FLOATS]
     _amax_next += 1
     return s
+
+
+def amax_vector(t: torch.Tensor, loose: float = 1.0) -> torch.Tensor:
+    """The bound vector of a tensor computed the slow way (tests, tools): max |t| x loose in slot 0, zeros elsewhere."""
+    v = torch.zeros(AMAX_FLOATS, device=t.device, dtype=_f32)
+    v[0] = t.detach().abs().max().to(_f32) * loose
+    return v
 
 
 # Bounds of GRADIENT tensors travel by address: autograd hands a backward node new Python objects for its incoming gradients, so an
@@ -135,7 +147,7 @@ def _get_amax(t: torch.Tensor):
     e = _grad_amax.get(t.data_ptr())
     if e is not None and e[1] == t.numel() and e[2] == _graph_task_id() and e[2] >= 0:
         if AMAX_CHECK:
-            got, bound = float(t.abs().max()), float(e[0])
+            got, bound = float(t.abs().max()), float(e[0].max())
             if not got <= bound:
                 raise RuntimeError(f"adm_amd: registered bound {bound} of a gradient tensor is below its maximum {got}")
         return e[0]

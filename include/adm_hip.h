@@ -23,6 +23,14 @@
 typedef struct ihipStream_t* hipStream_t;
 
 #ifdef __cplusplus
+/* A BOUND VECTOR (the `amax` arguments below): ADM_AMAX_SLOTS floats at a stride of ADM_AMAX_STRIDE floats (one cache line each), zeroed by
+ * the caller; the bound is the maximum of the slots.  The kernels that produce a tensor raise the slots with atomicMax, every wave
+ * on its own slot (tens of thousands of waves raising ONE address serialise in the L2: 185 us for a 22 us launch); the kernels that
+ * consume the tensor read all slots once per workgroup. */
+#define ADM_AMAX_SLOTS 64
+#define ADM_AMAX_STRIDE 32
+#define ADM_AMAX_FLOATS (ADM_AMAX_SLOTS * ADM_AMAX_STRIDE)
+
 extern "C" {
 #endif
 
@@ -113,8 +121,8 @@ int adm_wino2d_x6_splitk(int B, int H, int W, int Cin, int N);
 /* The same convolution on THREE fp16 products per f32 product (conv_wino2d_x6.hip, X6Fmt<1>): operands are split into two fp16 terms
  * by round-to-nearest after a power-of-two scaling, s a = h0 + h1 with |s a - h0 - h1| <= 2^-24 |s a| (h1 normal), and
  * a b ~ (h0 h0' + h0 h1' + h1 h0') / (s s').  wqh = adm_split2_f16 of the adm_pack_weight_wino2d planes with scale `wscale` (a power
- * of two; *overflow is raised if a scaled weight leaves the fp16 range), layout [ey][cols/16][ex][term(2)][rows][16].  amax_x: a DEVICE
- * float >= max |x| over the whole input (e.g. written by adm_gn_fwd_amax, which produced x); the kernel derives the activation scale
+ * of two; *overflow is raised if a scaled weight leaves the fp16 range), layout [ey][cols/16][ex][term(2)][rows][16].  amax_x: a bound
+ * vector (above) of |x| over the whole input (e.g. written by adm_gn_fwd_amax, which produced x); the kernel derives the activation scale
  * from it so that the Winograd input transform (sums of four values) stays inside the fp16 range.  Error against fp64: that of the
  * six-bf16-product form (tools/fp16x3_accuracy.py, tests/test_hip_ops.py).  up != 0: Conv2d(up=True) as adm_conv_fwd_wino2d_x6_up.
  * Replaces F.conv2d of uncond_unet.py:98-110 like the other forms. */
@@ -157,8 +165,8 @@ int adm_conv_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp2, float
                             int Cout, int lddy, int splits, int up, hipStream_t stream);
 int adm_gemm_wgrad_x6_bf16a(const void* x16, const float* dy, float* dwp, float* dbias, long P, int Cin, int ldx, int Cout, int lddy,
                             int splits, hipStream_t stream);
-/* ... and on the fp16 format of adm_conv_fwd_wino2d_h3 (two fp16 terms per operand, three products): amax_x / amax_dy = device
- * floats >= max|x| / max|dy| (written by the kernels that produced the tensors); det != 0 = the _ws contract (dwp = ws, dbias = bws,
+/* ... and on the fp16 format of adm_conv_fwd_wino2d_h3 (two fp16 terms per operand, three products): amax_x / amax_dy = bound vectors
+ * (above) of |x| / |dy|, written by the kernels that produced the tensors; det != 0 = the _ws contract (dwp = ws, dbias = bws,
  * splits from the _plan call).  Replaces the same autograd weight gradient (/root/reference/unet/uncond_unet.py:98-110). */
 int adm_conv_wgrad_x6_h3(const float* x, const float* dy, float* dwp2, float* dbias, int B, int H, int W, int Cin, int ldx, int Cout,
                          int lddy, int splits, int up, int det, const float* amax_x, const float* amax_dy, hipStream_t stream);
@@ -270,7 +278,7 @@ int adm_gn_apply(const float* x, const float* stats, const float* gamma, const f
 int adm_gn_fwd(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
                long ss_bstride, float* y, int B, int HW, int C, int G, float eps, int silu, float drop_p, uint64_t seed,
                hipStream_t stream);
-/* adm_gn_fwd that also raises the device float *amax (zeroed by the caller) to max |y| with one atomicMax per wave: the scale basis
+/* adm_gn_fwd that also raises the bound vector amax (above; zeroed by the caller) to max |y| with one atomicMax per wave: the scale basis
  * of the fp16-format convolution that consumes y (adm_conv_fwd_wino2d_h3). */
 int adm_gn_fwd_amax(const float* x, float* stats, double* ws, const float* gamma, const float* beta, const float* ss,
                     long ss_bstride, float* y, float* amax, int B, int HW, int C, int G, float eps, int silu, float drop_p,
@@ -296,7 +304,7 @@ int adm_gn_bwd_param_table(const long* table, int rows, long total_blocks, hipSt
 int adm_gn_bwd_add(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                    const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma, float* dbeta,
                    float* red, int B, int HW, int C, int G, int silu, float drop_p, uint64_t seed, hipStream_t stream);
-/* ... that also raises the device float *amax (zeroed by the caller) to max |dx|: the data-gradient convolution that consumes dx
+/* ... that also raises the bound vector amax (zeroed by the caller) to max |dx|: the data-gradient convolution that consumes dx
  * can then run on the fp16 format (adm_conv_fwd_wino2d_h3 with the data-gradient weight image). */
 int adm_gn_bwd_add_amax(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                         const float* ss, long ss_bstride, const float* addend, float* dx, float* dss, float* dgamma, float* dbeta,
@@ -356,7 +364,7 @@ int adm_add(const float* a, const float* b, float* y, long n, hipStream_t stream
 /* y = a + b (+ c when non-NULL), n % 4 == 0, 16-byte aligned: the sum of the gradients autograd would otherwise add pairwise for a
  * tensor with several consumers -- the encoder outputs feed the next block and both decoders' concatenations
  * (uncond_unet.py:548-571). */
-int adm_add3(const float* a, const float* b, const float* c, float* y, float* amax, long n, hipStream_t stream);     /* amax (may be NULL): raised to max |y| */
+int adm_add3(const float* a, const float* b, const float* c, float* y, float* amax, long n, hipStream_t stream);     /* amax (may be NULL): a bound vector, raised to max |y| */
 /* dst[m][dst_off + c] (+)= scale * src[m][src_off + c], c < C: channel concat / slice copies
  * (torch.cat, :571, :578; `scale` carries uncond_unet_sd_3's skip-tuning ratio) */
 int adm_copy_channels(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,

@@ -552,7 +552,8 @@ def test_schedule_kernels(ops):
 
 # ------------------------------------------------------------------------------------------------ fp16 split format (round 3)
 def _amax(t):
-    return t.abs().max().reshape(1).to(torch.float32)
+    from adm_amd import ops as _ops
+    return _ops.amax_vector(t)      # a bound vector (include/adm_hip.h): max |t| in slot 0
 
 
 @pytest.mark.parametrize("B,cin,cout,H,up", [(8, 64, 96, 32, False), (4, 192, 192, 16, False), (8, 96, 64, 16, True), (2, 32, 64, 8, False),
@@ -667,7 +668,8 @@ def test_group_norm_writes_the_maximum_for_its_consumer(ops, monkeypatch):
         for kw in (dict(), dict(drop_p=0.1, seed=7)):
             y = ops.group_norm_act(x, gam, bet, ss, silu=True, to_conv=True, **kw)
             assert hasattr(y, "_adm_amax"), "no maximum attached"
-            assert float(y._adm_amax) == float(y.abs().max()), (B, C, H, kw, float(y._adm_amax), float(y.abs().max()))
+            assert y._adm_amax.numel() == ops.AMAX_FLOATS              # a bound vector: the bound is the maximum of its slots
+            assert float(y._adm_amax.max()) == float(y.abs().max()), (B, C, H, kw, float(y._adm_amax.max()), float(y.abs().max()))
             assert ops.downsample2x(y)._adm_amax is y._adm_amax
         y0 = ops.group_norm_act(x, gam, bet, ss, silu=True)           # not promised to a conv: no maximum
         assert not hasattr(y0, "_adm_amax")

@@ -11,8 +11,8 @@ static void run(int B, int H, int Cin, int Cout) {
   for (auto& v : hx) v = (rand() / (float)RAND_MAX) * 2 - 1;
   for (auto& v : hy) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.05f;
   float *x, *dy, *w0, *w1, *b0, *b1, *am;
-  hipMalloc(&x, nx * 4); hipMalloc(&dy, ny * 4); hipMalloc(&w0, nw * 4); hipMalloc(&w1, nw * 4); hipMalloc(&b0, Cout * 4); hipMalloc(&b1, Cout * 4); hipMalloc(&am, 8);
-  { const float h[2] = {1.0f, 0.05f}; hipMemcpy(am, h, 8, hipMemcpyHostToDevice); }        // bounds of |x| and |dy|
+  hipMalloc(&x, nx * 4); hipMalloc(&dy, ny * 4); hipMalloc(&w0, nw * 4); hipMalloc(&w1, nw * 4); hipMalloc(&b0, Cout * 4); hipMalloc(&b1, Cout * 4); hipMalloc(&am, 2 * ADM_AMAX_FLOATS * 4); hipMemset(am, 0, 2 * ADM_AMAX_FLOATS * 4);
+  { const float hx1 = 1.0f, hy1 = 0.05f; hipMemcpy(am, &hx1, 4, hipMemcpyHostToDevice); hipMemcpy(am + ADM_AMAX_FLOATS, &hy1, 4, hipMemcpyHostToDevice); }        // bound vectors of |x| and |dy|
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(dy, hy.data(), ny * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms[4];
@@ -21,7 +21,7 @@ static void run(int B, int H, int Cin, int Cout) {
     auto call = [&]() {
       hipMemsetAsync(b, 0, Cout * 4, 0);
       adm_wgrad_h3_blocks(which == 3 ? 2 : 1);
-      return which >= 2 ? adm_conv_wgrad_x6_h3(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0, 0, am, am + 1, 0)
+      return which >= 2 ? adm_conv_wgrad_x6_h3(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0, 0, am, am + ADM_AMAX_FLOATS, 0)
            : which ? adm_conv_wgrad_x6(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0)
                    : adm_conv_wgrad_wino2d(x, dy, w, b, B, H, H, Cin, Cin, Cout, Cout, 0, 0);
     };

@@ -34,7 +34,7 @@ static void run(int B, int H, int Cin, int N, bool check) {
   if (check) adm_conv_fwd_wino2d(x, w, nullptr, nullptr, y2, nullptr, 0, B, H, H, Cin, Cin, N, N, N, N, 0);
   {   // fp16 format: 64-cout workgroups, then the wide (128-cout) form
     void* wh; float* am; int* flag;
-    hipMalloc(&wh, nw * 4); hipMalloc(&am, 4); hipMalloc(&flag, 4); hipMemset(flag, 0, 4);
+    hipMalloc(&wh, nw * 4); hipMalloc(&am, ADM_AMAX_FLOATS * 4); hipMemset(am, 0, ADM_AMAX_FLOATS * 4); hipMalloc(&flag, 4); hipMemset(flag, 0, 4);
     const float one = 1.0f; hipMemcpy(am, &one, 4, hipMemcpyHostToDevice);
     adm_split2_f16(w, wh, N, Cin, 2048.f, flag, 0);
     for (int wide : {0, 1, 3}) {
