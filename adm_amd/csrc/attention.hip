@@ -85,6 +85,18 @@ __device__ __forceinline__ void store_T(const f32x16 (&o)[2], float* rowptr, boo
     }
 }
 
+// max |o * scale| of the accumulators a lane stores with store_T (0 for lanes that store nothing)
+__device__ __forceinline__ float amax_T(const f32x16 (&o)[2], bool valid, float scale) {
+  float am = 0.f;
+  if (valid) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(o[db][r] * scale));
+  }
+  return am;
+}
+
 // Sequences longer than one chunk (CH = NKT*32 keys, at most 256) are processed flash-style: gridDim.y = number of
 // 256-row chunks the workgroup OWNS one of (queries for fwd / dq, keys for dkv) and it loops over all chunks of the
 // other side, re-filling LDS each time; the forward keeps a running max / sum per query (online softmax).
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_fwd_kernel(cons
 template <int NKT>
 __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dq_kernel(
     const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
-    const float* __restrict__ lse, float* __restrict__ dqkv, float* __restrict__ delta, int L, int heads) {
+    const float* __restrict__ lse, float* __restrict__ dqkv, float* __restrict__ delta, int L, int heads, float* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CH = NKT * 32;
   float* Ks = smem;
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dq_kernel(
     }
   }
   store_T(dq, dqkv + ((long)b * L + q) * rs + h * 192, qok, lh, 0.125f);
+  if (amax) adm_amax_commit(amax_T(dq, qok, 0.125f), amax);      // bound vector of |dqkv| (the qkv conv's gradients may run on the fp16 format)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dq_kernel(
 template <int NKT>
 __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dkv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, float* __restrict__ dqkv, int L, int heads) {
+    const float* __restrict__ delta, float* __restrict__ dqkv, int L, int heads, float* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CH = NKT * 32;
   float* Qs = smem;                          // [CH][KS]
@@ -279,11 +292,12 @@ __global__ __launch_bounds__(64 * (NKT > 8 ? 8 : NKT)) void attn_bwd_dkv_kernel(
   float* orow = dqkv + ((long)b * L + key) * rs + h * 192;
   store_T(dk, orow + 64, kok, lh, 0.125f);
   store_T(dv, orow + 128, kok, lh, 1.f);
+  if (amax) adm_amax_commit(fmaxf(amax_T(dk, kok, 0.125f), amax_T(dv, kok, 1.f)), amax);
 }
 
 template <int NKT>
 int launch_attn(int which, const float* qkv, const float* out, const float* dout, float* o_out, float* lse,
-                float* dqkv, float* delta, int B, int L, int heads, hipStream_t st) {
+                float* dqkv, float* delta, int B, int L, int heads, hipStream_t st, float* amax) {
   constexpr int NW = NKT > 8 ? 8 : NKT;
   const int smem_kv = NKT * 32 * KS * 2 * (int)sizeof(float);
   const int smem_dkv = smem_kv + NKT * 32 * 2 * (int)sizeof(float);
@@ -305,24 +319,24 @@ int launch_attn(int which, const float* qkv, const float* out, const float* dout
     if (grid.y > 1) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true>), grid, block, smem_kv, st, qkv, o_out, lse, L, heads);
     else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), grid, block, smem_kv, st, qkv, o_out, lse, L, heads);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT>), grid, block, smem_kv, st, qkv, out, dout, lse, dqkv, delta, L, heads);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT>), grid, block, smem_dkv, st, qkv, dout, lse, delta, dqkv, L, heads);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT>), grid, block, smem_kv, st, qkv, out, dout, lse, dqkv, delta, L, heads, amax);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT>), grid, block, smem_dkv, st, qkv, dout, lse, delta, dqkv, L, heads, amax);
   }
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
 
 int dispatch_attn(int which, const float* qkv, const float* out, const float* dout, float* o_out, float* lse,
-                  float* dqkv, float* delta, int B, int L, int heads, hipStream_t st) {
+                  float* dqkv, float* delta, int B, int L, int heads, hipStream_t st, float* amax = nullptr) {
   if (!qkv || B <= 0 || heads <= 0 || L <= 0 || L > 65536) return ADM_EINVAL;
   if (L > 32 && (L % 32) != 0) return ADM_EINVAL;
   if ((uintptr_t)qkv & 15) return ADM_EINVAL;
   const int nkt = L > 256 ? 8 : (L + 31) / 32;        // longer sequences: 256-row chunks, flash-style
   switch (nkt) {
-    case 1: return launch_attn<1>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st);
-    case 2: return launch_attn<2>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st);
-    case 4: return launch_attn<4>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st);
-    case 8: return launch_attn<8>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st);
+    case 1: return launch_attn<1>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st, amax);
+    case 2: return launch_attn<2>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st, amax);
+    case 4: return launch_attn<4>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st, amax);
+    case 8: return launch_attn<8>(which, qkv, out, dout, o_out, lse, dqkv, delta, B, L, heads, st, amax);
     default: return ADM_EINVAL;
   }
 }
@@ -338,4 +352,11 @@ extern "C" int adm_attn_bwd(const float* qkv, const float* out, const float* dou
                             float* delta, int B, int L, int heads, hipStream_t stream) {
   if (!out || !dout || !lse || !dqkv || !delta) return ADM_EINVAL;
   return dispatch_attn(1, qkv, out, dout, nullptr, const_cast<float*>(lse), dqkv, delta, B, L, heads, stream);
+}
+
+// adm_attn_bwd that also raises the bound vector amax (include/adm_hip.h; zeroed by the caller) to max |dqkv|
+extern "C" int adm_attn_bwd_amax(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                 float* delta, float* amax, int B, int L, int heads, hipStream_t stream) {
+  if (!out || !dout || !lse || !dqkv || !delta) return ADM_EINVAL;
+  return dispatch_attn(1, qkv, out, dout, nullptr, const_cast<float*>(lse), dqkv, delta, B, L, heads, stream, amax);
 }

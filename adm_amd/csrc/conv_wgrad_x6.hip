@@ -575,7 +575,9 @@ int wgrad_x6_1x1_impl(const float* x, const float* dy, float* dwp, float* dbias,
   p.Pp = (int)P; p.H = 0; p.W = 0; p.lw = 0; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.lddy = lddy; p.up = 0;
   p.xbytes = (int)xb; p.dybytes = (int)db;
   p.tilesN = adm_cdiv(Cin, XT);
-  const int cb = wgrad_cb(fmt, det, Cout);
+  // (64 pixels per stage, no transforms: the 128-cout form measured SLOWER here -- 7.9 vs 6.4 ms per step over the UNet's 69 launches --
+  //  so it is taken only when asked for: adm_wgrad_h3_blocks(2))
+  const int cb = g_wgrad_cb == 2 ? wgrad_cb(fmt, det, Cout) : 1;
   const long tiles = (long)adm_cdiv(Cout, XT * cb) * p.tilesN;
   constexpr int STEP = 4 * XK;
   const bool prezeroed = splits == ADM_SPLITS_AUTO_PREZEROED;

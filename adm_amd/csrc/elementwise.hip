@@ -129,15 +129,19 @@ __global__ void add3_kernel(const f32x4* __restrict__ a, const f32x4* __restrict
   adm_amax_commit(am, amax);                     // max |y| (a bound vector) for a fp16-format conv that consumes the sum (conv_wino2d_x6.hip)
 }
 __global__ void copy_channels_kernel(const float* __restrict__ src, int lds_, int src_off, float* __restrict__ dst,
-                                     int ldd, int dst_off, long M, int C4, float scale, int acc) {
+                                     int ldd, int dst_off, long M, int C4, float scale, int acc, float* __restrict__ amax) {
   long total = M * C4;
+  float am = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = i % C4;
     long m = i / C4;
     f32x4 v = *reinterpret_cast<const f32x4*>(src + m * lds_ + src_off + c * 4) * scale;
     f32x4* d = reinterpret_cast<f32x4*>(dst + m * ldd + dst_off + c * 4);
-    *d = acc ? *d + v : v;
+    if (acc) v += *d;
+    *d = v;
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
+  adm_amax_commit(am, amax);                     // (amax may be null) bound vector of what was written
 }
 
 // ---------------------------------------------------------------- SpatialAtt gate
@@ -678,7 +682,17 @@ extern "C" int adm_copy_channels(const float* src, int lds, int src_off, float* 
   if (!src || !dst || M <= 0 || C <= 0 || (C & 3) || (lds & 3) || (ldd & 3) || (src_off & 3) || (dst_off & 3))
     return ADM_EINVAL;
   hipLaunchKernelGGL(copy_channels_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, stream, src, lds, src_off, dst, ldd,
-                     dst_off, M, C / 4, scale, acc);
+                     dst_off, M, C / 4, scale, acc, static_cast<float*>(nullptr));
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+// ... that also raises the bound vector amax (include/adm_hip.h) to the maximum of what it wrote (the concatenation feeds 1x1 convs)
+extern "C" int adm_copy_channels_amax(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
+                                      float scale, int acc, float* amax, hipStream_t stream) {
+  if (!src || !dst || M <= 0 || C <= 0 || (C & 3) || (lds & 3) || (ldd & 3) || (src_off & 3) || (dst_off & 3))
+    return ADM_EINVAL;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, stream, src, lds, src_off, dst, ldd,
+                     dst_off, M, C / 4, scale, acc, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

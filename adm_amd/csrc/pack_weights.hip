@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 // (out-channel) x 32 (in-channel) tile of one layer: the tile's taps-interleaved source runs (32*taps contiguous floats per
 // out-channel) go through LDS once and leave as 128-byte row segments of every operand layout, so reads and writes are
 // coalesced (the previous element-per-thread gather ran at 0.7 TB/s and cost 3.8 ms per optimiser step).
-constexpr int PT_COLS = 22;      // 18, 19: fp16-format images of the 2-D Winograd operands; 20: their scale (float bits); 21: overflow flag (int*)
+constexpr int PT_COLS = 24;      // 18, 19: fp16-format images of the 2-D Winograd operands; 20: their scale (float bits); 21: overflow flag (int*); 22, 23: fp16-format images of the 1x1 operands (same scale and flag)
 __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict__ table, int n_entries) {
   __shared__ float tile[32][32 * 9 + 1];
   // layer of this tile: last row whose tile_begin <= blockIdx.x
@@ -140,6 +140,18 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
   // 1x1 layers on conv_gemm_x6.hip: the exact three-term bf16 split of both operands, [k/16][term][rows][16] (columns 16, 17)
   unsigned short* __restrict__ g6f = reinterpret_cast<unsigned short*>(t[16]);
   unsigned short* __restrict__ g6b = reinterpret_cast<unsigned short*>(t[17]);
+  // ... and their two-term fp16 images [k/16][term(2)][rows][16] of scale * w (conv_gemm_x6.hip FMT 1, adm_split2_rows_f16; columns 22, 23)
+  unsigned short* __restrict__ g6fh = reinterpret_cast<unsigned short*>(t[22]);
+  unsigned short* __restrict__ g6bh = reinterpret_cast<unsigned short*>(t[23]);
+  const float gscale = __uint_as_float((unsigned)t[20]);
+  bool gbad = false;
+  auto split2_store = [&](unsigned short* dh, long termh, float v) {
+    const float a = v * gscale;
+    gbad |= !(fabsf(a) < 65000.f);
+    const _Float16 h0 = (_Float16)a, h1 = (_Float16)(a - (float)h0);
+    dh[0] = __builtin_bit_cast(unsigned short, h0);
+    dh[termh] = __builtin_bit_cast(unsigned short, h1);
+  };
   auto split_store = [](unsigned short* d6, long term6, float v) {
     const unsigned b0 = __float_as_uint(v);
     const float r1 = v - __uint_as_float(b0 & 0xFFFF0000u);
@@ -158,6 +170,10 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
       const int k = ci0 + ci_l;
       split_store(g6f + ((((long)(k >> 4) * 3) * Co_pad + co0 + co_l) << 4) + (k & 15), (long)Co_pad << 4, v);
     }
+    if (g6fh && taps == 1) {
+      const int k = ci0 + ci_l;
+      split2_store(g6fh + ((((long)(k >> 4) * 2) * Co_pad + co0 + co_l) << 4) + (k & 15), (long)Co_pad << 4, v);
+    }
   }
   for (int e = threadIdx.x; e < n; e += 256) {     // data-gradient operand [Ci_pad][taps flipped][Co_pad]: co fastest
     const int co_l = e & 31, rest = e >> 5;
@@ -168,7 +184,12 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const long* __restrict_
       const int k = co0 + co_l;
       split_store(g6b + ((((long)(k >> 4) * 3) * Ci_pad + ci0 + ci_l) << 4) + (k & 15), (long)Ci_pad << 4, v);
     }
+    if (g6bh && taps == 1) {
+      const int k = co0 + co_l;
+      split2_store(g6bh + ((((long)(k >> 4) * 2) * Ci_pad + ci0 + ci_l) << 4) + (k & 15), (long)Ci_pad << 4, v);
+    }
   }
+  if (gbad && t[21]) *reinterpret_cast<int*>(t[21]) = 1;      // a scaled 1x1 weight left the fp16 range: the host falls back to the bf16 format
   if (taps != 9) return;
   // Winograd F(2,3) operands (conv_wino.hip): G g per filter row, u = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
   if (wf) {                                        // wf[xi][co][ky][ci]: ci fastest

@@ -39,6 +39,10 @@ _SIGS = {
     "adm_split2_f16": [P, P, I, I, F, P, P],
     "adm_conv_fwd_wino2d_h3": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, P, F, I, P],
     "adm_gemm_x6": [P, P, P, P, P, L, I, I, I, I, I, I, P],
+    "adm_gemm_x6_amax": [P, P, P, P, P, L, I, I, I, I, I, I, P, P],
+    "adm_gemm_x6_h3": [P, P, P, P, P, L, I, I, I, I, I, I, P, F, P, P],
+    "adm_split2_rows_f16": [P, P, I, I, I, F, P, P],
+    "adm_conv_fwd_wino2d_h3_amax": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, F, I, P, P],
     "adm_split3_rows": [P, P, I, I, I, P],
     "adm_conv_wgrad_x6": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_x6_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],
@@ -86,6 +90,7 @@ _SIGS = {
     "adm_posterior_sample": [P, I, P, P, I, L, I, F, P],
     "adm_attn_fwd": [P, P, P, I, I, I, P],
     "adm_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
+    "adm_attn_bwd_amax": [P, P, P, P, P, P, P, I, I, I, P],
     "adm_resample2x": [P, P, I, I, I, I, I, F, I, P],
     "adm_nchw_to_nhwc": [P, I, P, L, P, I, I, I, I, P],
     "adm_precond_out": [P, I, P, I, P, P, L, P, I, I, I, P],
@@ -97,6 +102,7 @@ _SIGS = {
     "adm_add": [P, P, P, L, P],
     "adm_add3": [P, P, P, P, P, L, P],
     "adm_copy_channels": [P, I, I, P, I, I, L, I, F, I, P],
+    "adm_copy_channels_amax": [P, I, I, P, I, I, L, I, F, I, P, P],
     "adm_spatial_att_fwd": [P, I, P, P, P, P, I, I, I, P],
     "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, P, I, I, I, P],
     "adm_q_sample": [P, P, P, P, I, L, I, P],

@@ -69,7 +69,7 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 # packed-weight cache
 # ------------------------------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "w2f6", "w2b6", "w2fh", "w2bh", "g6f", "g6b", "src")
+    __slots__ = ("key", "fwd", "bwd", "bias", "fwd16", "bwd16", "wf", "wb", "w2f", "w2b", "w2f6", "w2b6", "w2fh", "w2bh", "g6f", "g6b", "g6fh", "g6bh", "src")
 
 
 # Contraction precision of the conv / Linear kernels: "f32" (default: exact fp32 MFMA) or "bf16" (BASELINE
@@ -99,6 +99,7 @@ BF16X6 = os.environ.get("ADM_BF16X6", "1") != "0"
 # ADM_FP16X3=0 keeps every split kernel on the bf16 format.
 FP16X3 = os.environ.get("ADM_FP16X3", "1") != "0"
 H3_WGRAD = os.environ.get("ADM_FP16X3_WGRAD", "1") != "0"      # ... also for the weight gradients
+H3_GEMM = os.environ.get("ADM_FP16X3_GEMM", "1") != "0"        # ... and for the 1x1 convs (conv_gemm_x6.hip FMT 1), which takes bounds of conv / attention / concat OUTPUTS
 H3_WSCALE = 2048.0
 _h3_flag = None             # device int32: raised by the weight split kernels on overflow
 _h3_checks = 0
@@ -315,20 +316,32 @@ def _use_gemm_x6(M: int, ks: int, up, n_p: int, k_p: int) -> bool:
     return BF16X6 and ks == 1 and not up and M >= GEMM_X6_MIN_M and n_p % 128 == 0 and k_p % 32 == 0
 
 
-def _gemm_x6_operands(ent: "_Packed"):
-    """[K/16][3][rows][16] bf16 images of a packed 1x1 operand pair (forward: rows = couts; data gradient: rows = cins)."""
-    if ent.g6f is None:
-        ent.g6f = torch.empty((3,) + tuple(ent.fwd.shape), device=ent.fwd.device, dtype=torch.bfloat16)
-        ent.g6b = torch.empty((3,) + tuple(ent.bwd.shape), device=ent.bwd.device, dtype=torch.bfloat16)
-        _resplit_gemm_x6(ent)
-        global _pack_table
-        _pack_table = None           # the one-launch repack table must learn the new destinations
-    return ent.g6f, ent.g6b
+def _gemm_x6_operand(ent: "_Packed", which: int):
+    """[K/16][3][rows][16] bf16 image of a packed 1x1 operand (which = 0 forward: rows = couts; 1 data gradient: rows = cins), built on
+    first use (only the direction that is asked for), refreshed by repack_all() afterwards."""
+    global _pack_table
+    name = "g6b" if which else "g6f"
+    if getattr(ent, name) is None:
+        src = ent.bwd if which else ent.fwd
+        img = torch.empty((3,) + tuple(src.shape), device=src.device, dtype=torch.bfloat16)
+        call("adm_split3_rows", ptr(src), ptr(img), src.shape[0], src.shape[1], src.shape[1])
+        setattr(ent, name, img)
+        _pack_table = None           # the one-launch repack table must learn the new destination
+    return getattr(ent, name)
 
 
-def _resplit_gemm_x6(ent: "_Packed"):
-    for src, dst in ((ent.fwd, ent.g6f), (ent.bwd, ent.g6b)):
-        call("adm_split3_rows", ptr(src), ptr(dst), src.shape[0], src.shape[1], src.shape[1])
+def _gemm_h3_operand(ent: "_Packed", which: int):
+    """[K/16][2][rows][16] fp16 image (scale H3_WSCALE) of a packed 1x1 operand: which = 0 forward (rows = couts), 1 data gradient (rows =
+    cins); built on first use, refreshed by repack_all() afterwards."""
+    global _pack_table
+    name = "g6bh" if which else "g6fh"
+    if getattr(ent, name) is None:
+        src = ent.bwd if which else ent.fwd
+        img = torch.empty((2,) + tuple(src.shape), device=src.device, dtype=torch.float16)
+        call("adm_split2_rows_f16", ptr(src), ptr(img), src.shape[0], src.shape[1], src.shape[1], H3_WSCALE, ptr(_h3_flag_tensor(src)))
+        setattr(ent, name, img)
+        _pack_table = None           # the one-launch repack table must learn the new destination
+    return getattr(ent, name)
 
 
 _pack_epoch = 0     # bumped by code that rewrites parameters through raw pointers (fused optimiser)
@@ -355,6 +368,7 @@ def packed(weight: torch.Tensor, bias: Optional[torch.Tensor], ks: int, qkv: boo
     ent.w2f6 = ent.w2b6 = None
     ent.w2fh = ent.w2bh = None
     ent.g6f = ent.g6b = None
+    ent.g6fh = ent.g6bh = None
     ent.src = (co, ci, ks, qkv)
     ent.fwd = _new((cop, ks * ks * cip), w)
     ent.bwd = _new((cip, ks * ks * cop), w)
@@ -391,6 +405,7 @@ _pack_table = None          # (device int64 table, [entries], total 32x32 tiles,
 
 
 _H3_WSCALE_BITS = int.from_bytes(__import__("struct").pack("<f", H3_WSCALE), "little")
+PACK_TABLE_COLS = 24        # = PT_COLS of csrc/pack_weights.hip: a row of adm_pack_weight_table
 
 
 def repack_all():
@@ -420,7 +435,10 @@ def repack_all():
                          0 if ent.w2f6 is None else ent.w2f6.data_ptr(), 0 if ent.w2b6 is None else ent.w2b6.data_ptr(),
                          0 if ent.g6f is None else ent.g6f.data_ptr(), 0 if ent.g6b is None else ent.g6b.data_ptr(),
                          0 if ent.w2fh is None else ent.w2fh.data_ptr(), 0 if ent.w2bh is None else ent.w2bh.data_ptr(),
-                         _H3_WSCALE_BITS, 0 if ent.w2fh is None and ent.w2bh is None else _h3_flag_tensor(w).data_ptr()])
+                         _H3_WSCALE_BITS,
+                         0 if (ent.w2fh is None and ent.w2bh is None and ent.g6fh is None and ent.g6bh is None) else _h3_flag_tensor(w).data_ptr(),
+                         0 if ent.g6fh is None else ent.g6fh.data_ptr(), 0 if ent.g6bh is None else ent.g6bh.data_ptr()])
+            assert len(rows[-1]) == PACK_TABLE_COLS
             tiles += (cop // 32) * (cip // 32)         # column 9 = exclusive prefix sum of 32x32 tiles
             ents.append((wref, bref, ks, qkv, ent))
         if not rows:
@@ -824,16 +842,34 @@ class _Conv(torch.autograd.Function):
         wq2 = _wino2_operands(weight, pk, 0) if (wino2 and not h3) else None
         wq = _wino_operands(weight, pk)[0] if (wino and not wino2) else None
         g6 = not use_bf16 and _use_gemm_x6(_sel_batch(B) * Ho * Wo, ks, up, cop, cip)
-        kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wino2 else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
+        g6h = g6 and FP16X3 and H3_GEMM and amax is not None
+        # the bound of the OUTPUT, for the 1x1 convs / concatenations that consume it: written by the epilogues of the two kernels below
+        global _conv_amax_out
+        _conv_amax_out = None
+        want_out = FP16X3 and H3_GEMM and BF16X6 and not bf16 and x.is_cuda
+        kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wino2 else "wino" if wq is not None else ("gemmh3" if g6h else "gemmx6") if g6 else "igemm"
         with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                    f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
             if h3:
                 sk = 1 if _SELECT_BATCH is not None else hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cip, cop)
-                wsk = _new((sk * B * Ho * Wo * cop,), x) if sk > 1 else None
-                call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk, 0)), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
-                     0 if wsk is None else wsk.numel(), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up))
+                if sk == 1 and want_out:
+                    _conv_amax_out = _amax_slot(x)
+                    call("adm_conv_fwd_wino2d_h3_amax", ptr(x), ptr(_h3_operands(weight, pk, 0)), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo,
+                         cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up), ptr(_conv_amax_out))
+                else:
+                    wsk = _new((sk * B * Ho * Wo * cop,), x) if sk > 1 else None
+                    call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk, 0)), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
+                         0 if wsk is None else wsk.numel(), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up))
+            elif g6h:
+                _conv_amax_out = _amax_slot(x) if want_out else None
+                call("adm_gemm_x6_h3", ptr(x), ptr(_gemm_h3_operand(pk, 0)), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
+                     cop, cop, cop, ptr(amax), H3_WSCALE, ptr(_conv_amax_out))
+            elif g6 and want_out:
+                _conv_amax_out = _amax_slot(x)
+                call("adm_gemm_x6_amax", ptr(x), ptr(_gemm_x6_operand(pk, 0)), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
+                     cop, cop, cop, ptr(_conv_amax_out))
             elif g6:
-                call("adm_gemm_x6", ptr(x), ptr(_gemm_x6_operands(pk)[0]), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
+                call("adm_gemm_x6", ptr(x), ptr(_gemm_x6_operand(pk, 0)), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,
                      cop, cop, cop)
             elif use_bf16:
                 call("adm_conv_fwd_bf16a" if x16 is not None else "adm_conv_fwd_bf16", ptr(x16 if x16 is not None else x),
@@ -1019,7 +1055,9 @@ class _Conv(torch.autograd.Function):
             wq2 = _wino2_operands(weight, pk, 1) if (wino2 and not h3) else None
             wq = _wino_operands(weight, pk)[1] if (wino and not wino2) else None
             g6 = not use_bf16 and _use_gemm_x6(B * Ho * Wo, ks, up, cip, cop)
-            kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wino2 else "wino" if wq is not None else "gemmx6" if g6 else "igemm"
+            amax_g = _get_amax(dy) if (g6 and FP16X3 and H3_GEMM) else None
+            g6h = amax_g is not None
+            kind = ("wino2h3" if h3 else "wino2x6" if BF16X6 else "wino2") if wino2 else "wino" if wq is not None else ("gemmh3" if g6h else "gemmx6") if g6 else "igemm"
             with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                        f"dgrad{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cip} K={ks * ks * cop}"):
                 if h3:
@@ -1027,8 +1065,11 @@ class _Conv(torch.autograd.Function):
                     wsk = _new((sk * B * Ho * Wo * cip,), dy) if sk > 1 else None
                     call("adm_conv_fwd_wino2d_h3", ptr(dy), ptr(_h3_operands(weight, pk, 1)), None, None, ptr(dxf), ptr(wsk),
                          0 if wsk is None else wsk.numel(), B, Ho, Wo, cop, cop, cip, cip, cip, cip, ptr(amax_dy), H3_WSCALE, 0)
+                elif g6h:
+                    call("adm_gemm_x6_h3", ptr(dy), ptr(_gemm_h3_operand(pk, 1)), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
+                         cip, cip, ptr(amax_g), H3_WSCALE, None)
                 elif g6:
-                    call("adm_gemm_x6", ptr(dy), ptr(_gemm_x6_operands(pk)[1]), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
+                    call("adm_gemm_x6", ptr(dy), ptr(_gemm_x6_operand(pk, 1)), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
                          cip, cip)
                 elif use_bf16:
                     call("adm_conv_fwd_bf16", ptr(dy), ptr(_bf16_operand(pk, "bwd")), None, None, ptr(dxf), B, Ho, Wo,
@@ -1051,7 +1092,18 @@ def conv2d(x, weight, bias=None, residual=None, *, up=False, qkv=False, tile=-1,
     (default: the one a GroupNorm kernel attached to x) -- lets the 3x3 layers run on the fp16 split format."""
     if amax is None:
         amax = getattr(x, "_adm_amax", None)
-    return _Conv.apply(x, weight, bias, residual, weight.shape[-1] if weight.dim() == 4 else 1, bool(up), bool(qkv), tile, amax)
+    if AMAX_CHECK and amax is not None:
+        got, bound = float(x.detach().abs().max()), float(amax.max())
+        if not got <= bound:
+            raise RuntimeError(f"adm_amd: the bound {bound} that came with a conv input is below its maximum {got}")
+    global _conv_amax_out
+    y = _Conv.apply(x, weight, bias, residual, weight.shape[-1] if weight.dim() == 4 else 1, bool(up), bool(qkv), tile, amax)
+    if _conv_amax_out is not None:       # the kernel's epilogue wrote the bound of y (bias and residual included)
+        y._adm_amax, _conv_amax_out = _conv_amax_out, None
+    return y
+
+
+_conv_amax_out = None       # bound vector of the last conv forward's output (handed from _Conv.forward to conv2d(), as _gn_amax_out)
 
 
 def linear(x, weight, bias=None, residual=None):
@@ -1221,6 +1273,9 @@ def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0
     wa = _want_amax(to_conv, x)
     y, xo = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), True, out16,
                                 None, None, wa)
+    a = getattr(x, "_adm_amax", None)
+    if a is not None:
+        xo._adm_amax = a             # (xo is x: the skip / residual branch keeps its bound)
     return (_attach_bf16(y) if out16 else (_attach_amax(y) if wa else y)), xo
 
 
@@ -1303,7 +1358,7 @@ class AffineGroup:
             # the LDS-tiled table kernel with ONE row: the [total][K] operand as the source of its own forward image (an in-place
             # identity) and of the [K][total] data-gradient image (adm_pack_weight's element-wise transpose: 0.50 ms; this: ~0.13)
             if self.t_table is None:
-                row = [self.wcat.data_ptr(), self.wcat.data_ptr(), self.wcat_t.data_ptr(), self.total, self.K, 1, self.total, self.K, 0, 0] + [0] * 8
+                row = [self.wcat.data_ptr(), self.wcat.data_ptr(), self.wcat_t.data_ptr(), self.total, self.K, 1, self.total, self.K, 0, 0] + [0] * (PACK_TABLE_COLS - 10)
                 self.t_table = torch.tensor([row], dtype=torch.int64).to(self.wcat.device)
             call("adm_pack_weight_table", ptr(self.t_table), 1, (self.total // 32) * (self.K // 32))
             self.sig_t = self.sig
@@ -1433,13 +1488,22 @@ class _Attention(torch.autograd.Function):
         B, H, W, _ = qkv.shape
         dqkv = _like(qkv)
         delta = _like(lse)
+        slot_a = _amax_slot(qkv) if (FP16X3 and H3_GEMM and BF16X6 and COMPUTE == "f32") else None     # max |dqkv| for the qkv conv's gradients
         with _Prof("attn", 10.0 * (H * W) ** 2 * 64 * B * ctx.heads):
-            call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)
+            if slot_a is not None:
+                call("adm_attn_bwd_amax", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ptr(slot_a), B, H * W, ctx.heads)
+            else:
+                call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)
+        _reg_amax(dqkv, slot_a)
         return dqkv, None
 
 
 def attention(qkv, heads: int):
-    return _Attention.apply(qkv, heads)
+    out = _Attention.apply(qkv, heads)
+    a = getattr(qkv, "_adm_amax", None)
+    if a is not None:
+        out._adm_amax = a            # rows of softmax(q k^T) v are convex combinations of rows of v: |out| <= max |v| <= max |qkv|
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1488,8 +1552,14 @@ class _Concat(torch.autograd.Function):
         ca, cb = a.shape[-1], b.shape[-1]
         M = a.numel() // ca
         y = _new((*a.shape[:-1], ca + cb), a)
-        call("adm_copy_channels", ptr(a), ca, 0, ptr(y), ca + cb, 0, M, ca, 1.0, 0)
-        call("adm_copy_channels", ptr(b), cb, 0, ptr(y), ca + cb, ca, M, cb, float(scale_b), 0)
+        global _cat_amax_out
+        _cat_amax_out = slot = _amax_slot(a) if (FP16X3 and H3_GEMM and BF16X6 and COMPUTE == "f32" and a.is_cuda) else None
+        if slot is not None:         # the concatenation feeds a block's 1x1 skip conv: the copies leave the bound of what they wrote
+            call("adm_copy_channels_amax", ptr(a), ca, 0, ptr(y), ca + cb, 0, M, ca, 1.0, 0, ptr(slot))
+            call("adm_copy_channels_amax", ptr(b), cb, 0, ptr(y), ca + cb, ca, M, cb, float(scale_b), 0, ptr(slot))
+        else:
+            call("adm_copy_channels", ptr(a), ca, 0, ptr(y), ca + cb, 0, M, ca, 1.0, 0)
+            call("adm_copy_channels", ptr(b), cb, 0, ptr(y), ca + cb, ca, M, cb, float(scale_b), 0)
         ctx.meta = (ca, cb, scale_b)
         return y
 
@@ -1546,11 +1616,23 @@ def fanout(x, n: int):
     """n aliases of x for n consumers (the gradient sum is one HIP launch); without a graph to record, x itself n times."""
     if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * max(n, 1)
-    return _Fanout.apply(x, n)
+    outs = _Fanout.apply(x, n)
+    a = getattr(x, "_adm_amax", None)
+    if a is not None:
+        for o in outs:
+            o._adm_amax = a          # (aliases of x)
+    return outs
+
+
+_cat_amax_out = None
 
 
 def concat_channels(a, b, scale_b: float = 1.0):
-    return _Concat.apply(a, b, scale_b)
+    global _cat_amax_out
+    y = _Concat.apply(a, b, scale_b)
+    if _cat_amax_out is not None:
+        y._adm_amax, _cat_amax_out = _cat_amax_out, None
+    return y
 
 
 class _Silu(torch.autograd.Function):

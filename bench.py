@@ -314,9 +314,9 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         # wino2x6: f32 products carried by SIX bf16 MFMAs (exact three-term split): its MFMA pipe executes 6 x 4/9 of the algorithmic
         # flops as bf16 flops and is priced against the bf16 peak
-        PEAKS = {"wgrad_wino2h3": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmh3": PEAK_BF16_MFMA_TFLOPS, "wino2h3": PEAK_BF16_MFMA_TFLOPS, "wino2x6": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2x6": PEAK_BF16_MFMA_TFLOPS, "gemmx6": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmx6": PEAK_BF16_MFMA_TFLOPS}
-        PMC_CLASS = {"wgrad_wino2h3": "wgrad_x6", "wgrad_gemmh3": "wgrad_x6", "wino2h3": "wino2d_x6", "wino2x6": "wino2d_x6", "wino2": "wino2d", "wgrad_wino2": "wgrad_wino2d", "wgrad_wino2x6": "wgrad_x6", "gemmx6": "gemm_x6", "wgrad_gemmx6": "wgrad_x6", "attn": "attn"}
-        EXEC = {"wgrad_wino2h3": 3.0 * 4.0 / 9.0, "wgrad_gemmh3": 3.0, "wino2h3": 3.0 * 4.0 / 9.0, "wino2x6": 6.0 * 4.0 / 9.0, "wgrad_wino2x6": 6.0 * 4.0 / 9.0, "gemmx6": 6.0, "wgrad_gemmx6": 6.0, "wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino2": 4.0 / 9.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
+        PEAKS = {"gemmh3": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2h3": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmh3": PEAK_BF16_MFMA_TFLOPS, "wino2h3": PEAK_BF16_MFMA_TFLOPS, "wino2x6": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2x6": PEAK_BF16_MFMA_TFLOPS, "gemmx6": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmx6": PEAK_BF16_MFMA_TFLOPS}
+        PMC_CLASS = {"gemmh3": "gemm_x6", "wgrad_wino2h3": "wgrad_x6", "wgrad_gemmh3": "wgrad_x6", "wino2h3": "wino2d_x6", "wino2x6": "wino2d_x6", "wino2": "wino2d", "wgrad_wino2": "wgrad_wino2d", "wgrad_wino2x6": "wgrad_x6", "gemmx6": "gemm_x6", "wgrad_gemmx6": "wgrad_x6", "attn": "attn"}
+        EXEC = {"gemmh3": 3.0, "wgrad_wino2h3": 3.0 * 4.0 / 9.0, "wgrad_gemmh3": 3.0, "wino2h3": 3.0 * 4.0 / 9.0, "wino2x6": 6.0 * 4.0 / 9.0, "wgrad_wino2x6": 6.0 * 4.0 / 9.0, "gemmx6": 6.0, "wgrad_gemmx6": 6.0, "wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino2": 4.0 / 9.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
         NAMES = {"wino2h3": "wino2d_x6_kernel<1> (3x3 conv forward, 2-D Winograd F(2x2,3x3); f32 products as THREE fp16 MFMAs on a two-term "
                             "round-to-nearest fp16 split scaled by the operand's max (written by the GroupNorm kernel), f32 accumulate)",
                  "wino2x6": "wino2d_x6_kernel<0> (3x3 conv forward + data-gradient, 2-D Winograd F(2x2,3x3); f32 products as six bf16 MFMAs "
@@ -326,6 +326,7 @@ def main():
                  "igemm": ("igemm_f32_kernel" if args.dtype == "f32" else "igemm_bf16_kernel") +
                           " (1x1 / Linear / small-map / fused-upsample convs: forward + data-gradient)",
                  "wgrad_gemmx6": "wgrad_x6_kernel<1> (1x1 weight gradients with >= 8192 pixels; f32 products as six bf16 MFMAs)",
+                 "gemmh3": "gemm_x6_kernel<1> (1x1 convs with >= 8192 pixels whose input came with a bound, forward + data-gradient; three fp16 MFMAs per f32 product)",
                  "gemmx6": "gemm_x6_kernel (1x1 convs with >= 8192 pixels, forward + data-gradient; f32 products as six bf16 MFMAs)",
                  "wgrad_wino2x6": "wgrad_x6_kernel (3x3 weight gradient, 2-D Winograd F(3x3,2x2); f32 products as six bf16 MFMAs on the "
                                   "exact three-term bf16 split of both operands, f32 accumulate)",
@@ -353,7 +354,7 @@ def main():
                  "sustained_clock_GHz_pmc": pmc_all.get(pc, {}).get("effective_clock_GHz")}
             if kind in ("wgrad_wino2x6", "wgrad_wino2h3"):
                 e["f32_equivalent"] = round(fl * 4.0 / 9.0 / ms / 1e9, 2)
-            if kind in ("gemmx6", "wgrad_gemmx6", "wgrad_gemmh3"):
+            if kind in ("gemmx6", "gemmh3", "wgrad_gemmx6", "wgrad_gemmh3"):
                 e["f32_equivalent"] = round(fl / ms / 1e9, 2)
             if kind == "wino2h3":
                 e["f32_equivalent"] = round(fl * 4.0 / 9.0 / ms / 1e9, 2)
@@ -379,7 +380,7 @@ def main():
                      "convention": "achieved = EXECUTED MFMA flops / kernel time (HIP events around every launch of one profiled step); "
                              "frac = achieved / peak.  Winograd executes 4/9 (2-D F(2x2,3x3)) or 2/3 (1-D F(2,3)) of the direct convolution's flops: "
                              "`algorithmic` is the direct-convolution rate (SURVEY 8d's 213.9 GFLOP/image figures)."})
-        for kind, key in (("wino2x6", "wino2d_x6"), ("wino2h3", "wino2d_h3"), ("wino2", "wino2d_f32"), ("wino", "wino_1d"), ("igemm", "igemm_direct"), ("gemmx6", "gemm_x6"), ("wgrad_wino2x6", "wgrad_x6"), ("wgrad_wino2h3", "wgrad_h3"), ("wgrad_gemmx6", "wgrad_gemm_x6"), ("wgrad_gemmh3", "wgrad_gemm_h3"), ("wgrad_wino2", "wgrad_wino2d"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
+        for kind, key in (("wino2x6", "wino2d_x6"), ("wino2h3", "wino2d_h3"), ("wino2", "wino2d_f32"), ("wino", "wino_1d"), ("igemm", "igemm_direct"), ("gemmx6", "gemm_x6"), ("gemmh3", "gemm_h3"), ("wgrad_wino2x6", "wgrad_x6"), ("wgrad_wino2h3", "wgrad_h3"), ("wgrad_gemmx6", "wgrad_gemm_x6"), ("wgrad_gemmh3", "wgrad_gemm_h3"), ("wgrad_wino2", "wgrad_wino2d"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
             if kind in by and kind != dom_kind:
                 roof[key] = mfma_entry(kind)
         # whole step against the MFMA roof: every GEMM-shaped launch of the profiled step

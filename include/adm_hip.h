@@ -130,6 +130,10 @@ int adm_split2_f16(const float* src, void* dst, int rows, int cols, float scale,
 int adm_conv_fwd_wino2d_h3(const float* x, const void* wqh, const float* bias, const float* res, float* y, float* ws,
                            long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                            const float* amax_x, float wscale, int up, hipStream_t stream);
+/* ... that also raises the bound vector amax_y to max |y| (bias and residual included) for the kernels that consume y; never split-K */
+int adm_conv_fwd_wino2d_h3_amax(const float* x, const void* wqh, const float* bias, const float* res, float* y, int B, int H, int W,
+                                int Cin, int ldx, int N, int wrows, int ldy, int ldr, const float* amax_x, float wscale, int up,
+                                float* amax_y, hipStream_t stream);
 /* dst (48 * rows * cols bf16, layout [ey][cols/16][ex][term][rows][16]) <- exact split a = a0 + a1 + a2 of the sixteen Winograd
  * planes src[ey * 4 + ex][rows][cols] (f32) */
 int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t stream);
@@ -139,6 +143,15 @@ int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t
 int adm_gemm_x6(const float* x, const void* w6, const float* bias, const float* res, float* y, long M, int K, int ldx, int N, int wrows,
                 int ldy, int ldr, hipStream_t stream);
 int adm_split3_rows(const float* src, void* dst, int rows, int cols, int ld, hipStream_t stream);
+/* adm_gemm_x6 that also raises the bound vector amax_y (above) to max |y| */
+int adm_gemm_x6_amax(const float* x, const void* w6, const float* bias, const float* res, float* y, long M, int K, int ldx, int N,
+                     int wrows, int ldy, int ldr, float* amax_y, hipStream_t stream);
+/* ... on the fp16 format (two fp16 terms per operand, three MFMAs per f32 product, as adm_conv_fwd_wino2d_h3): wh = adm_split2_rows_f16 of
+ * the packed operand = [K/16][2][wrows][16] fp16 of wscale * w (*overflow raised if a scaled weight leaves the fp16 range), amax_x = bound
+ * vector of |x|, amax_y (may be NULL) = bound vector raised to max |y|.  Same replacement (uncond_unet.py:98-110). */
+int adm_gemm_x6_h3(const float* x, const void* wh, const float* bias, const float* res, float* y, long M, int K, int ldx, int N, int wrows,
+                   int ldy, int ldr, const float* amax_x, float wscale, float* amax_y, hipStream_t stream);
+int adm_split2_rows_f16(const float* src, void* dst, int rows, int cols, int ld, float scale, int* overflow, hipStream_t stream);
 /* The 2-D Winograd weight gradient with the f32 products on the bf16 MFMA by exact three-term splitting (conv_wgrad_x6.hip): same
  * contract as adm_conv_wgrad_wino2d (dwp2[Cout][4 ey][3 kx][Cin] -> adm_unpack_wgrad_wino2d; dbias += column sums of dy; splits = 0:
  * chosen by the launcher; H, W powers of two >= 2).  _ws: deterministic mode, split z stores its partial planes at ws[z][Cout][12][Cin]
@@ -332,6 +345,9 @@ int adm_attn_fwd(const float* qkv, float* out, float* lse, int B, int L, int hea
  * follows); delta [B*heads][L] scratch.  dqkv has the qkv layout.  Autograd of :205-208. */
 int adm_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
                  int B, int L, int heads, hipStream_t stream);
+/* ... that also raises the bound vector amax to max |dqkv| (the qkv conv's gradients then run on the fp16 format) */
+int adm_attn_bwd_amax(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta, float* amax,
+                      int B, int L, int heads, hipStream_t stream);
 
 /* ---------------- resampling / layout / elementwise ------------------------------------------ */
 
@@ -369,6 +385,9 @@ int adm_add3(const float* a, const float* b, const float* c, float* y, float* am
  * (torch.cat, :571, :578; `scale` carries uncond_unet_sd_3's skip-tuning ratio) */
 int adm_copy_channels(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
                       float scale, int acc, hipStream_t stream);
+/* ... that also raises the bound vector amax to the maximum of what it wrote */
+int adm_copy_channels_amax(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
+                           float scale, int acc, float* amax, hipStream_t stream);
 /* out[b,i] = a[b] * x[b,i] + s[b] * y[b,i]  (x may be NULL -> s*y only; x fp32 or fp64): the
  * single-decoder variants' D_y = (x - (sigma-1) D_x) / g(sigma)  (uncond_unet_sd.py:602) and its backward */
 int adm_axpby_b(const void* x, int x_is_f64, const float* y, const float* a, const float* s, long coef_bstride,

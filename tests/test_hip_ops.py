@@ -592,7 +592,7 @@ def test_conv_h3_forward_vs_torch(ops, monkeypatch, request, B, cin, cout, H, up
                                                     (2, 32, 64, 8, 3, False, False), (128, 384, 384, 4, 3, False, False),
                                                     (8, 384, 384, 32, 1, False, False), (9, 192, 96, 32, 1, False, True),
                                                     (4, 64, 160, 16, 3, True, False), (33, 96, 224, 16, 1, False, False)])
-@pytest.mark.parametrize("blocks", [-1, 1])
+@pytest.mark.parametrize("blocks", [-1, 1, 2])
 def test_conv_h3_weight_gradient_vs_torch(ops, monkeypatch, request, B, cin, cout, H, ks, up, det, blocks):
     """Weight and bias gradients on the fp16 format (conv_wgrad_x6.hip FMT 1: adm_conv_wgrad_x6_h3 / adm_gemm_wgrad_x6_h3) against
     autograd's on the CPU: 3x3 (plain, fused nearest x2, split over many workgroups, the deterministic workspace mode) and 1x1; the
@@ -601,7 +601,7 @@ def test_conv_h3_weight_gradient_vs_torch(ops, monkeypatch, request, B, cin, cou
     monkeypatch.setattr(ops, "WINO_MIN_M", 1)
     monkeypatch.setattr(ops, "DETERMINISTIC", det)
     from adm_amd import hip as _hip
-    old_blocks = _hip.lib().adm_wgrad_h3_blocks(blocks)      # -1: 128 couts per workgroup (sixteen waves) where > 64 couts; 1: 64
+    old_blocks = _hip.lib().adm_wgrad_h3_blocks(blocks)      # -1: 128 couts per workgroup (sixteen waves) for the 3x3 form where > 64 couts; 2: also for the 1x1 form; 1: 64
     request.addfinalizer(lambda: _hip.lib().adm_wgrad_h3_blocks(old_blocks))
     x = fill.hash_tensor((B, cin, H, H), f"hwx{cin}{H}", 1.0)
     w = fill.hash_tensor((cout, cin, ks, ks), f"hww{cin}{cout}", 1.0 / math.sqrt(cin * ks * ks))
@@ -628,6 +628,53 @@ def test_conv_h3_weight_gradient_vs_torch(ops, monkeypatch, request, B, cin, cou
         errs[(mode, loose)] = float((wd.grad.double().cpu() - wr.grad).abs().max()) / scale
     print(f"dW error / max sum|x dy|: three fp16 {errs[('h3', 1.0)]:.3e} (bound x 8: {errs[('h3', 8.0)]:.3e}), six bf16 {errs[('x6', 1.0)]:.3e}")
     assert errs[("h3", 1.0)] <= max(2.0 * errs[("x6", 1.0)], 2e-7) and errs[("h3", 8.0)] <= max(4.0 * errs[("x6", 1.0)], 4e-7), errs
+
+
+@pytest.mark.parametrize("B,cin,cout,H,qkv,with_res", [(8, 384, 384, 32, False, True), (9, 192, 384, 31, False, False), (8, 384, 1152, 32, True, False),
+                                                        (32, 768, 128, 16, False, True)])
+def test_conv1x1_h3_forward_backward(ops, monkeypatch, B, cin, cout, H, qkv, with_res):
+    """1x1 convs on the fp16 format (conv_gemm_x6.hip FMT 1: adm_gemm_x6_h3): forward (bias, residual, the qkv row permutation, ragged
+    pixel counts), data gradient and -- through conv_wgrad_x6.hip MODE 1 FMT 1 -- weight / bias gradients against F.conv2d on the CPU;
+    the launch record proves the format; the bound the epilogue leaves on the output is EXACTLY max |y|; error vs fp64 at the
+    six-bf16 form's."""
+    x = fill.hash_tensor((B, cin, H, H), f"g3x{cin}{cout}", 1.0)
+    w = fill.hash_tensor((cout, cin, 1, 1), f"g3w{cin}{cout}", 1.0 / math.sqrt(cin))
+    b = fill.hash_tensor((cout,), f"g3b{cin}{cout}", 0.5)
+    r = fill.hash_tensor((B, cout, H, H), f"g3r{cin}{cout}", 1.0)
+    gy = fill.hash_tensor((B, cout, H, H), f"g3g{cin}{cout}", 2.0)
+    xr, wr, br = [t.double().clone().requires_grad_(True) for t in (x, w, b)]
+    y_ref = F.conv2d(xr, wr, br) + (r.double() if with_res else 0)
+    (y_ref * gy.double()).sum().backward()
+    s_y = float(F.conv2d(x.double().abs(), w.double().abs()).max())
+    errs = {}
+    for mode in ("h3", "x6"):
+        monkeypatch.setattr(ops, "H3_GEMM", mode == "h3")
+        monkeypatch.setattr(ops, "_get_amax", (lambda t: _amax(t) * 2.0) if mode == "h3" else (lambda t: None))      # dy's bound, loose by 2
+        xd = nhwc(x).requires_grad_(True)
+        wd, bd = torch.nn.Parameter(dev(w)), torch.nn.Parameter(dev(b))
+        monkeypatch.setattr(ops, "PROFILE", [])
+        y = ops.conv2d(xd, wd, bd, nhwc(r) if with_res else None, qkv=qkv, amax=_amax(dev(x)))
+        kinds = [k[0] for k in ops.PROFILE]
+        assert kinds == ["gemm" + mode], kinds
+        if mode == "h3":
+            assert float(y._adm_amax.max()) == float(y.detach().abs().max())       # the epilogue's bound of the output
+        yn = nchw(y)
+        if qkv:
+            heads = cout // 192
+            yn = yn.reshape(B, heads, 3, 64, H, H).permute(0, 1, 3, 2, 4, 5).reshape(B, cout, H, H)
+        close(yn, y_ref.detach().float())
+        errs[mode] = float((yn.double() - y_ref.detach()).abs().max()) / s_y
+        if qkv:
+            continue
+        monkeypatch.setattr(ops, "PROFILE", [])
+        (y * nhwc(gy)).sum().backward()
+        kinds = [k[0] for k in ops.PROFILE]
+        assert kinds.count("gemm" + mode) == (1 if cin % 128 == 0 else 0) and kinds.count("wgrad_gemm" + mode) == 1, kinds
+        close(nchw(xd.grad), xr.grad.float())
+        close(wd.grad, wr.grad.float())
+        close(bd.grad, br.grad.float())
+    print(f"1x1 forward error / max sum|ab|: three fp16 {errs['h3']:.3e}, six bf16 {errs['x6']:.3e}")
+    assert errs["h3"] <= max(2.0 * errs["x6"], 2e-7), errs
 
 
 def test_conv_h3_error_vs_fp64(ops, monkeypatch):
