@@ -54,7 +54,6 @@ struct X6P {
   int ybytes, rbytes;                  // > 0: y / res fit 32-bit byte offsets (branch-free buffer epilogue)
   int up;                              // 1: x is [B][H/2][W/2][ldx] and the conv runs on its nearest x2 up-sampling (Conv2d(up=True))
   const float* amax_x; float wscale;   // fp16 format only: bound vector (adm_hip.h) of |x|; the weights' (power-of-two) scale
-  float* amax_y;                       // (may be null; not with split-K) bound vector raised to max |y| by the epilogue
 };
 
 typedef __attribute__((address_space(3))) void x6_lds_void;
@@ -474,7 +473,6 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
   const int n = n0 + wn * 32 + lr;
   const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
   const int tb = mt0 + wm * 32 + 4 * lh;
-  float am_y = 0.f;
   if (p.ybytes > 0) {
     // branch-free: residual loads and output stores through buffer descriptors, masked lanes at an out-of-range offset (a missing
     // residual = an empty descriptor: reads return 0).  With `if`s per element the compiler serialises the 64 residual loads of a
@@ -502,19 +500,16 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float v = (FMT ? Y[a][c][r] * inv_scale : Y[a][c][r]) + bv + rv[a][c];
-          if (ok) am_y = fmaxf(am_y, fabsf(v));
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)oy[a][c], 0, 0);
-        }
+        for (int c = 0; c < 2; ++c)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (FMT ? Y[a][c][r] * inv_scale : Y[a][c][r]) + bv + rv[a][c]), rs_y, (int)oy[a][c], 0, 0);
     }
-    if (p.splitk == 1) adm_amax_commit(am_y, p.amax_y);      // (every consumer wave arrives here with all lanes)
     return;
   }
+  if (n >= p.N) return;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int t = tb + (r & 3) + 8 * (r >> 2);
-    if (t >= p.Mt || n >= p.N) continue;
+    if (t >= p.Mt) continue;
     const int xp = t % p.Wh;
     const int u = t / p.Wh;                        // = b * Hh + ty
     const long px0 = ((long)u * 2) * p.W + 2 * xp; // pixel (b, 2ty, 2xp) in units of pixels: (b*H + 2ty) * W + 2xp
@@ -523,12 +518,10 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
       const long px = px0 + (long)a * p.W;
       float y0 = (FMT ? Y[a][0][r] * inv_scale : Y[a][0][r]) + bv, y1 = (FMT ? Y[a][1][r] * inv_scale : Y[a][1][r]) + bv;
       if (p.res) { y0 += p.res[px * p.ldr + n]; y1 += p.res[(px + 1) * p.ldr + n]; }
-      am_y = fmaxf(am_y, fmaxf(fabsf(y0), fabsf(y1)));
       p.y[px * p.ldy + n] = y0;
       p.y[(px + 1) * p.ldy + n] = y1;
     }
   }
-  if (p.splitk == 1) adm_amax_commit(am_y, p.amax_y);
 }
 
 // Operand layout of the kernel: Wq6[ey][chunk][ex][term][n][16] -- the twelve 16-channel images a stage needs for its 64 rows are
@@ -610,7 +603,7 @@ extern "C" int adm_wino2d_h3_wide(int v) { const int old = g_h3_wide; g_h3_wide 
 
 static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws, long ws_floats,
                             int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, int up, hipStream_t stream,
-                            const float* amax_x = nullptr, float wscale = 0.f, float* amax_y = nullptr) {
+                            const float* amax_x = nullptr, float wscale = 0.f) {
   const bool h3 = amax_x != nullptr;                   // fp16 format: wq6 is the adm_split2_f16 image (scale wscale), amax_x >= max |x| on the device
   if (!x || !wq6 || !y || B <= 0 || H < 2 || W < 2 || (W & 1) || (H & 1)) return ADM_EINVAL;
   if ((Cin & 31) || (ldx & 3) || N <= 0 || wrows < N) return ADM_EINVAL;      // an even number of 16-channel chunks
@@ -623,7 +616,7 @@ static int wino2d_x6_launch(const float* x, const void* wq6, const float* bias, 
   if (Mt >= (1L << 30) || xb >= (1L << 31) || wb >= (1L << 31)) return ADM_EINVAL;
   p.Mt = (int)Mt; p.N = N; p.H = H; p.W = W; p.Hh = H / 2; p.Wh = W / 2; p.Cin = Cin; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
   p.wrows = wrows; p.xbytes = (int)xb; p.wbytes = (int)wb; p.plane = wrows * Cin; p.up = up ? 1 : 0;
-  p.amax_x = amax_x; p.wscale = wscale; p.amax_y = amax_y;
+  p.amax_x = amax_x; p.wscale = wscale;
   p.tilesN = adm_cdiv(N, X6N);
   const long mtiles = adm_cdiv(Mt, X6P_T);
   p.splitk = 1; p.chunks_per_split = 0; p.ws = X6_TL ? ws : nullptr;
@@ -693,14 +686,6 @@ extern "C" int adm_conv_fwd_wino2d_h3(const float* x, const void* wqh, const flo
                                       const float* amax_x, float wscale, int up, hipStream_t stream) {
   if (!amax_x) return ADM_EINVAL;
   return wino2d_x6_launch(x, wqh, bias, res, y, ws, ws_floats, B, H, W, Cin, ldx, N, wrows, ldy, ldr, up, stream, amax_x, wscale);
-}
-// ... that also raises the bound vector amax_y to max |y| (bias and residual included).  Only launches without split-K do (ws = NULL
-// guarantees that): the split-K reduction writes y in another kernel.
-extern "C" int adm_conv_fwd_wino2d_h3_amax(const float* x, const void* wqh, const float* bias, const float* res, float* y, int B, int H,
-                                           int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr, const float* amax_x,
-                                           float wscale, int up, float* amax_y, hipStream_t stream) {
-  if (!amax_x) return ADM_EINVAL;
-  return wino2d_x6_launch(x, wqh, bias, res, y, nullptr, 0, B, H, W, Cin, ldx, N, wrows, ldy, ldr, up, stream, amax_x, wscale, amax_y);
 }
 
 extern "C" int adm_conv_fwd_wino2d_x6(const float* x, const void* wq6, const float* bias, const float* res, float* y, float* ws,

@@ -42,7 +42,6 @@ _SIGS = {
     "adm_gemm_x6_amax": [P, P, P, P, P, L, I, I, I, I, I, I, P, P],
     "adm_gemm_x6_h3": [P, P, P, P, P, L, I, I, I, I, I, I, P, F, P, P],
     "adm_split2_rows_f16": [P, P, I, I, I, F, P, P],
-    "adm_conv_fwd_wino2d_h3_amax": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, F, I, P, P],
     "adm_split3_rows": [P, P, I, I, I, P],
     "adm_conv_wgrad_x6": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "adm_conv_wgrad_x6_up": [P, P, P, P, I, I, I, I, I, I, I, I, P],

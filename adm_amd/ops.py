@@ -843,7 +843,7 @@ class _Conv(torch.autograd.Function):
         wq = _wino_operands(weight, pk)[0] if (wino and not wino2) else None
         g6 = not use_bf16 and _use_gemm_x6(_sel_batch(B) * Ho * Wo, ks, up, cop, cip)
         g6h = g6 and FP16X3 and H3_GEMM and amax is not None
-        # the bound of the OUTPUT, for the 1x1 convs / concatenations that consume it: written by the epilogues of the two kernels below
+        # the bound of a 1x1 conv's OUTPUT (qkv -> attention -> proj; proj + residual -> the next block's skip conv): written by the epilogue
         global _conv_amax_out
         _conv_amax_out = None
         want_out = FP16X3 and H3_GEMM and BF16X6 and not bf16 and x.is_cuda
@@ -851,15 +851,12 @@ class _Conv(torch.autograd.Function):
         with _Prof(kind, 2.0 * B * Ho * Wo * co * ci * ks * ks,
                    f"fwd{'-' + kind if kind != 'igemm' else ''} M={B * Ho * Wo} N={cop} K={ks * ks * cip}"):
             if h3:
+                # (no output bound from this kernel: tracking it in the epilogue cost the 96- / 128-cout forms ten more spilled registers,
+                #  +10 % on their launches, for the handful of encoder skip convs that would have used it)
                 sk = 1 if _SELECT_BATCH is not None else hip.lib().adm_wino2d_x6_splitk(B, Ho, Wo, cip, cop)
-                if sk == 1 and want_out:
-                    _conv_amax_out = _amax_slot(x)
-                    call("adm_conv_fwd_wino2d_h3_amax", ptr(x), ptr(_h3_operands(weight, pk, 0)), ptr(pk.bias), ptr(res), ptr(y), B, Ho, Wo,
-                         cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up), ptr(_conv_amax_out))
-                else:
-                    wsk = _new((sk * B * Ho * Wo * cop,), x) if sk > 1 else None
-                    call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk, 0)), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
-                         0 if wsk is None else wsk.numel(), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up))
+                wsk = _new((sk * B * Ho * Wo * cop,), x) if sk > 1 else None
+                call("adm_conv_fwd_wino2d_h3", ptr(x), ptr(_h3_operands(weight, pk, 0)), ptr(pk.bias), ptr(res), ptr(y), ptr(wsk),
+                     0 if wsk is None else wsk.numel(), B, Ho, Wo, cip, cip, cop, cop, cop, cop, ptr(amax), H3_WSCALE, int(up))
             elif g6h:
                 _conv_amax_out = _amax_slot(x) if want_out else None
                 call("adm_gemm_x6_h3", ptr(x), ptr(_gemm_h3_operand(pk, 0)), ptr(pk.bias), ptr(res), ptr(y), B * Ho * Wo, cip, cip, cop,

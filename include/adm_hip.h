@@ -130,10 +130,6 @@ int adm_split2_f16(const float* src, void* dst, int rows, int cols, float scale,
 int adm_conv_fwd_wino2d_h3(const float* x, const void* wqh, const float* bias, const float* res, float* y, float* ws,
                            long ws_floats, int B, int H, int W, int Cin, int ldx, int N, int wrows, int ldy, int ldr,
                            const float* amax_x, float wscale, int up, hipStream_t stream);
-/* ... that also raises the bound vector amax_y to max |y| (bias and residual included) for the kernels that consume y; never split-K */
-int adm_conv_fwd_wino2d_h3_amax(const float* x, const void* wqh, const float* bias, const float* res, float* y, int B, int H, int W,
-                                int Cin, int ldx, int N, int wrows, int ldy, int ldr, const float* amax_x, float wscale, int up,
-                                float* amax_y, hipStream_t stream);
 /* dst (48 * rows * cols bf16, layout [ey][cols/16][ex][term][rows][16]) <- exact split a = a0 + a1 + a2 of the sixteen Winograd
  * planes src[ey * 4 + ex][rows][cols] (f32) */
 int adm_split3_bf16(const float* src, void* dst, int rows, int cols, hipStream_t stream);
