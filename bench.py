@@ -358,9 +358,15 @@ def main():
                 e["f32_equivalent"] = round(fl / ms / 1e9, 2)
             if kind == "wino2h3":
                 e["f32_equivalent"] = round(fl * 4.0 / 9.0 / ms / 1e9, 2)
+                e["f32_equivalent_over_f32_mfma_peak"] = round(fl * 4.0 / 9.0 / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)
                 e["note"] = ("three fp16 MFMAs per f32 product (two-term round-to-nearest split after a power-of-two scaling by the operand's "
                              "maximum): `achieved` = executed fp16 MFMA flops / kernel time against the dense 16-bit MFMA peak; error vs fp64 = "
-                             "the six-bf16 form's (tests/test_hip_ops.py::test_conv_h3_error_vs_fp64)")
+                             "the six-bf16 form's (tests/test_hip_ops.py::test_conv_h3_error_vs_fp64).  Halving the executed flops per product "
+                             "LOWERED this fraction (round 2: 0.29 with six products) while the kernel got 1.46x faster: `f32_equivalent` = the "
+                             "f32 products per second it delivers, `f32_equivalent_over_f32_mfma_peak` = that against the f32 MFMA pipe it "
+                             "replaces.  The kernel is bound by the path from the L2 into the CU, not by the matrix pipe: a stage of a 96-cout "
+                             "workgroup fetches 56 KB in ~2400 cycles = 23-24 B/clk per CU against ~30 B/clk deliverable with every CU asking "
+                             "(DESIGN.md section 4, 'The fetch bound'; workgroup forms are chosen by bytes fetched per MFMA)")
             if kind == "wino2x6":
                 e["f32_equivalent"] = round(fl * 4.0 / 9.0 / ms / 1e9, 2)
                 e["note"] = ("`achieved` = executed bf16 MFMA flops (six bf16 products per f32 product x 4/9 of the direct convolution's "
