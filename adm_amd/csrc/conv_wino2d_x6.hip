@@ -41,6 +41,9 @@
 #ifndef X6_TL
 #define X6_TL 0      // diagnostic build: per-stage timeline of one consumer and one producer wave of workgroup 0 into p.ws (tools/bench_wino2d_x6.cpp)
 #endif
+#ifndef X6_SHARE
+#define X6_SHARE 0   // 1: patch columns shared between neighbouring tiles by cross-lane moves (measured slower: see the producer)
+#endif
 #ifndef X6_ABL
 #define X6_ABL 0     // diagnostic builds (tools/bench_wino2d_x6.cpp): 1 no A global loads, 2 no A transform / split / LDS stores, 4 no B DMA, 8 no MFMAs, 16 no LDS fragment reads
 #endif
@@ -230,6 +233,14 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
     const int ptid = wid * 64 + lane;
     const int pl = ptid >> 2, aq = ptid & 3;          // tile, channel quad
     unsigned a_base = 0, colmask = 0, rowmask = 0;
+    // Patch columns shared between neighbouring tiles: tile xp reads input columns 2xp - 1 .. 2xp + 2, so its column 0 is column 2 of
+    // tile xp - 1 and its column 3 is column 1 of tile xp + 1 -- tiles that sit FOUR LANES away in this wave (thread = (tile, quad)).
+    // With X6_SHARE a lane whose neighbour is in its wave and its tile row takes the y-combined value from it with one cross-lane
+    // move per dword instead of asking for the same bytes again: half the activation requests of a stage.  Correct (the parity suite
+    // passes with it) and SLOWER on every shape (tools/bench_wino2d_x6.cpp, 128 x 32 x 32 x 384 -> 384: 0.905 -> 1.106 ms with 64
+    // couts, 0.789 -> 0.865 with 128): the repeated columns were L1 hits, and the eight ds_bpermute per thread and stage are LDS
+    // operations, which do not overlap with the MFMAs of the SIMD's other waves.  Off by default; not for the fused up-sampling.
+    bool take_l = false, take_r = false;
     {
       const int t = mt0 + pl;
       if (t < p.Mt) {
@@ -240,6 +251,12 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
                       : (unsigned)((((long)b * p.H + 2 * ty) * p.W + 2 * xp) * p.ldx + aq * 4) * 4u;
         colmask = (xp > 0 ? 1u : 0u) | 6u | (2 * xp + 2 < p.W ? 8u : 0u);
         rowmask = (ty > 0 ? 1u : 0u) | 6u | (2 * ty + 2 < p.H ? 8u : 0u);
+        if (X6_SHARE && !p.up) {
+          take_l = xp > 0 && (pl & 15) != 0;                // (tile pl - 1 = lane - 4 of this wave, same tile row)
+          take_r = xp + 1 < p.Wh && (pl & 15) != 15 && t + 1 < p.Mt;
+          if (take_l) colmask &= ~1u;                       // no request for what the neighbour loads
+          if (take_r) colmask &= ~8u;
+        }
       }
     }
     // rows are 32 bytes; a 16-lane group of a fragment read covers 16 rows at one 16-byte half, i.e. only half of the banks, unless
@@ -291,6 +308,13 @@ __global__ __launch_bounds__((2 * NB + 4) * 64) void wino2d_x6_kernel(X6P p) {
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = p_sub4(dA[d][j], dB[d][j]);
+      }
+      if (X6_SHARE && !p.up) {                          // (uniform) every lane takes part in the moves
+        f32x4 el, er;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { el[i] = __shfl_up(e[2][i], 4, 64); er[i] = __shfl_down(e[1][i], 4, 64); }
+        if (take_l) e[0] = el;
+        if (take_r) e[3] = er;
       }
       if (FMT) h3_store(e, la + slot * F::A_STAGE, sa);
       else x6_store(e, la + slot * F::A_STAGE);
