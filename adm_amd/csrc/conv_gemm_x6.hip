@@ -11,7 +11,7 @@
 //     over two stages (24 matrix adds from C = 0) and are then added to the running totals with f32 adds;
 //   * weights: split once per optimiser step into Wg6[chunk][term][n][16] (adm_split3_rows), one contiguous KB per LDS-DMA
 //     instruction, three stages ahead; LDS: A 2 x 24 KB + B 4 x 24 KB.
-// Used for 1x1 convs with M >= 8192, N % 128 == 0, K % 32 == 0 (ADM_BF16X6=0 keeps them on conv_igemm.hip).
+// Used for 1x1 convs with M >= 8192, N >= 128 (a ragged last 128-cout tile reads zero rows), K % 32 == 0 (ADM_BF16X6=0 keeps them on conv_igemm.hip).
 // Replaces F.conv2d (1x1) of Conv2d.forward and its data gradient (/root/reference/unet/uncond_unet.py:98-110).
 #include "common.h"
 #include "../../include/adm_hip.h"
