@@ -139,9 +139,11 @@ _grad_amax = {}
 
 def _reg_amax(t: torch.Tensor, slot):
     if slot is not None:
-        if len(_grad_amax) > 8192:
-            _grad_amax.clear()
-        _grad_amax[t.data_ptr()] = (slot, t.numel(), _graph_task_id())
+        tid = _graph_task_id()
+        if len(_grad_amax) > 8192:       # forget the entries of earlier backward passes (never this pass's: their consumers are still to come)
+            for k in [k for k, e in _grad_amax.items() if e[2] != tid]:
+                del _grad_amax[k]
+        _grad_amax[t.data_ptr()] = (slot, t.numel(), tid)
 
 
 def _get_amax(t: torch.Tensor):
@@ -303,7 +305,7 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed", which: int):
     return getattr(ent, name)
 
 
-GEMM_X6_MIN_M = 8192
+GEMM_X6_MIN_M = int(os.environ.get("ADM_GEMM_X6_MIN_M", "8192"))
 # The 1x1 WEIGHT gradient on the split-bf16 kernel (conv_wgrad_x6.hip MODE 1: four 16-pixel chunks in place of the four ex planes).
 # With the first version of that kernel it was no faster than the f32 direct kernel (65-103 vs 47-111 TFLOP/s per shape); on the
 # twelve-wave version (one plane per consumer wave, 64 x 64 tiles) it is: 84-126 vs 51-109 TFLOP/s on every 1x1 shape of the UNet
@@ -1250,26 +1252,27 @@ def _attach_bf16(y):
     return y
 
 
-def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5, to_conv=False):
+def group_norm_act(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5, to_conv=False, bound=False):
     """groups = 0: the UNet's min(32, C // 4) (uncond_unet.py:119-129); the KL autoencoder passes 32 / 1e-6
     (ddm/encoder_decoder.py:56-57).  to_conv=True promises that the ONLY consumer of the result is ops.conv2d: in the bf16-storage
     mode the values are then written as bf16 and the returned f32 tensor is an unwritten carrier (see _GroupNormAct.forward)."""
     out16 = bool(to_conv) and bf16_storage()
     slot = getattr(scale_shift, "_adm_dss", None) if scale_shift is not None else None       # (set by affine_group())
-    wa = _want_amax(to_conv, x)
+    wa = _want_amax(to_conv or bound, x)      # bound=True: the consumer is a conv behind a 2x2 mean (which keeps the bound)
     y = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), False, out16,
                             None if slot is None else slot[0], None if slot is None else slot[1], wa)
     return _attach_bf16(y) if out16 else (_attach_amax(y) if wa else y)
 
 
-def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5, to_conv=False):
+def group_norm_act_fork(x, gamma, beta, scale_shift=None, *, silu=True, drop_p=0.0, seed=0, groups=0, eps=1e-5, to_conv=False, bound=False):
     """(group_norm_act(x), x): the second output is x itself, to be used by the residual branch of a block.  In backward
     the residual branch's gradient arrives together with the normalised branch's, and is added inside the GroupNorm
     backward kernel instead of by a separate autograd accumulation pass (4 instead of 12 bytes per element)."""
     if not (torch.is_grad_enabled() and x.requires_grad):
-        return group_norm_act(x, gamma, beta, scale_shift, silu=silu, drop_p=drop_p, seed=seed, groups=groups, eps=eps, to_conv=to_conv), x
+        return group_norm_act(x, gamma, beta, scale_shift, silu=silu, drop_p=drop_p, seed=seed, groups=groups, eps=eps, to_conv=to_conv,
+                              bound=bound), x
     out16 = bool(to_conv) and bf16_storage()
-    wa = _want_amax(to_conv, x)
+    wa = _want_amax(to_conv or bound, x)
     y, xo = _GroupNormAct.apply(x, gamma, beta, scale_shift, bool(silu), float(drop_p), int(seed), int(groups), float(eps), True, out16,
                                 None, None, wa)
     a = getattr(x, "_adm_amax", None)

@@ -99,10 +99,10 @@ class GroupNorm(nn.Module):
         seed = ops.next_dropout_seed() if drop_p > 0 else 0
         return ops.group_norm_act(x, self.weight, self.bias, scale_shift, silu=silu, drop_p=drop_p, seed=seed, to_conv=to_conv)
 
-    def fork(self, x, silu=False, to_conv=False):
+    def fork(self, x, silu=False, to_conv=False, bound=False):
         """(norm(x), x): x comes back for the residual branch so that both gradients are summed inside the GroupNorm
-        backward kernel (ops.group_norm_act_fork)."""
-        return ops.group_norm_act_fork(x, self.weight, self.bias, None, silu=silu, to_conv=to_conv)
+        backward kernel (ops.group_norm_act_fork).  bound: also leave max |norm(x)| for a conv further down (ops.group_norm_act)."""
+        return ops.group_norm_act_fork(x, self.weight, self.bias, None, silu=silu, to_conv=to_conv, bound=bound)
 
 
 _AFFINE_GROUPS = weakref.WeakKeyDictionary()      # DhariwalUNet -> (ops.AffineGroup over its blocks' `affine` Linears, the blocks)
@@ -137,7 +137,7 @@ class UNetBlock(nn.Module):
     def forward(self, x, emb, ss=None):
         """ss: this block's scale/shift when the caller computed all blocks' `affine` Linears as one GEMM (ops.affine_group)."""
         # (to_conv: these normalised tensors go straight into a conv -- conv0 resamples first when it down-samples)
-        n0, x = self.norm0.fork(x, silu=True, to_conv=not self.conv0.down)    # x feeds the normalised branch AND the residual / skip branch
+        n0, x = self.norm0.fork(x, silu=True, to_conv=not self.conv0.down, bound=True)    # x feeds the normalised branch AND the residual / skip branch
         h = self.conv0(n0)
         p = self.dropout if self.training else 0.0
         h = self.norm1(h, self.affine(emb) if ss is None else ss, silu=True, drop_p=p, to_conv=True)
