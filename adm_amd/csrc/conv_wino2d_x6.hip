@@ -183,7 +183,10 @@ __device__ __forceinline__ void x6_store(const f32x4 (&e)[4], unsigned short* la
 // Stage order shared by both roles: K blocks of X6_KB chunks outermost, the four ey passes inside a block, chunks innermost
 // (a stage = one (ey, chunk) pair).  Inside a (block, ey) group the MFMA accumulators run on (<= 24 matrix adds each); at its end
 // they are transformed and added to the output rows with f32 adds.
-constexpr int X6_KB = 4;
+#ifndef X6_KB_N
+#define X6_KB_N 4
+#endif
+constexpr int X6_KB = X6_KB_N;
 // With the fused nearest x2 up-sampling the patch rows r1 and r2 are the SAME source row, so the pass ey = 2 (r2 - r1) is
 // identically zero and is skipped (three passes per block).
 struct X6Seq {
