@@ -204,7 +204,9 @@ class DDPMBase(nn.Module):
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
+            ops.new_amax_pool()                    # the bound vectors of this graph: allocated and zero-filled inside the capture
             C, noise = self.model(x, t)
+        ops.new_amax_pool()                        # (eager launches must not write into the graph's private memory)
         ent = {"graph": graph, "x": x, "t": t, "C": C, "noise": noise, "epoch": ops._pack_epoch}
         cache[key] = ent
         return ent

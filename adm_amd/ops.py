@@ -104,6 +104,7 @@ H3_WSCALE = 2048.0
 _h3_flag = None             # device int32: raised by the weight split kernels on overflow
 _h3_checks = 0
 _amax_pool, _amax_next = None, 0
+_amax_pool_captured, _amax_pool_size = False, 0
 _AMAX_POOL = 4096
 
 
@@ -115,12 +116,25 @@ def _amax_slot(like: torch.Tensor) -> torch.Tensor:
     max |output| -- every wave raises its own slot: one address for all of them serialised the atomics of a launch (185 us for
     a 22 us add3).  Vectors come from a pool that is zero-filled once per 4096 vectors (no per-call fill launch); a vector lives as
     long as a tensor refers to it."""
-    global _amax_pool, _amax_next
-    if _amax_pool is None or _amax_next >= _AMAX_POOL or _amax_pool.device != like.device:
-        _amax_pool, _amax_next = torch.zeros(_AMAX_POOL * AMAX_FLOATS, device=like.device, dtype=_f32), 0
+    global _amax_pool, _amax_next, _amax_pool_captured, _amax_pool_size
+    # Under HIP-graph capture (the sampler's replayed forward) the pool is allocated INSIDE the capture, so that its zero fill is part
+    # of the graph and every replay starts from zeroed vectors: bounds never carry over from an earlier replay (a larger stale bound
+    # would only change the scale by a power of two -- but replays are promised bit-identical to eager launches).
+    capturing = like.is_cuda and torch.cuda.is_current_stream_capturing()
+    if (_amax_pool is None or _amax_next >= _amax_pool_size or _amax_pool.device != like.device
+            or capturing != _amax_pool_captured):
+        _amax_pool_size = 1024 if capturing else _AMAX_POOL
+        _amax_pool, _amax_next = torch.zeros(_amax_pool_size * AMAX_FLOATS, device=like.device, dtype=_f32), 0
+        _amax_pool_captured = capturing
     s = _amax_pool[_amax_next * AMAX_FLOATS:(_amax_next + 1) * AMAX_FLOATS]
     _amax_next += 1
     return s
+
+
+def new_amax_pool():
+    """The next bound vector comes from a fresh pool (HIP-graph capture: ddm/ddpm.py)."""
+    global _amax_pool
+    _amax_pool = None
 
 
 def amax_vector(t: torch.Tensor, loose: float = 1.0) -> torch.Tensor:
