@@ -128,6 +128,32 @@ __global__ void add3_kernel(const f32x4* __restrict__ a, const f32x4* __restrict
   }
   adm_amax_commit(am, amax);                     // max |y| (a bound vector) for a fp16-format conv that consumes the sum (conv_wino2d_x6.hip)
 }
+// y[m] = (a[m] | scale_b * b[m]) in one launch (dir 0: torch.cat of two NHWC tensors along the channels), or its adjoint (dir 1:
+// a[m] = y[m][:Ca], b[m] = scale_b * y[m][Ca:]); amax (dir 0, may be null): bound vector of what was written
+__global__ void concat2_kernel(float* __restrict__ a, int Ca4, float* __restrict__ b, int Cb4, float* __restrict__ y, long M, float scale_b,
+                               int dir, float* __restrict__ amax) {
+  const int C4 = Ca4 + Cb4;
+  const long total = M * C4;
+  float am = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const long m = i / C4;
+    f32x4* yp = reinterpret_cast<f32x4*>(y) + i;
+    const bool first = c < Ca4;
+    f32x4* sp = first ? reinterpret_cast<f32x4*>(a) + m * Ca4 + c : reinterpret_cast<f32x4*>(b) + m * Cb4 + (c - Ca4);
+    if (dir == 0) {
+      f32x4 v = *sp;
+      if (!first) v *= scale_b;
+      *yp = v;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    } else {
+      f32x4 v = *yp;
+      if (!first) v *= scale_b;
+      *sp = v;
+    }
+  }
+  if (dir == 0) adm_amax_commit(am, amax);
+}
 __global__ void copy_channels_kernel(const float* __restrict__ src, int lds_, int src_off, float* __restrict__ dst,
                                      int ldd, int dst_off, long M, int C4, float scale, int acc, float* __restrict__ amax) {
   long total = M * C4;
@@ -686,16 +712,23 @@ extern "C" int adm_copy_channels(const float* src, int lds, int src_off, float* 
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
-// ... that also raises the bound vector amax (include/adm_hip.h) to the maximum of what it wrote (the concatenation feeds 1x1 convs)
-extern "C" int adm_copy_channels_amax(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
-                                      float scale, int acc, float* amax, hipStream_t stream) {
-  if (!src || !dst || M <= 0 || C <= 0 || (C & 3) || (lds & 3) || (ldd & 3) || (src_off & 3) || (dst_off & 3))
-    return ADM_EINVAL;
-  hipLaunchKernelGGL(copy_channels_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, stream, src, lds, src_off, dst, ldd,
-                     dst_off, M, C / 4, scale, acc, amax);
+// torch.cat((a, scale_b * b), channels) of two NHWC tensors in ONE launch: y[M][Ca + Cb]; amax (may be NULL): bound vector of y
+extern "C" int adm_concat2(const float* a, int Ca, const float* b, int Cb, float* y, long M, float scale_b, float* amax, hipStream_t stream) {
+  if (!a || !b || !y || M <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 3) || (Cb & 3)) return ADM_EINVAL;
+  hipLaunchKernelGGL(concat2_kernel, dim3(ew_grid(M * ((Ca + Cb) / 4))), dim3(256), 0, stream, const_cast<float*>(a), Ca / 4,
+                     const_cast<float*>(b), Cb / 4, y, M, scale_b, 0, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
+// its adjoint in one launch: da[M][Ca] = dy[:, :Ca], db[M][Cb] = scale_b * dy[:, Ca:]
+extern "C" int adm_split2(const float* dy, float* da, int Ca, float* db, int Cb, long M, float scale_b, hipStream_t stream) {
+  if (!dy || !da || !db || M <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 3) || (Cb & 3)) return ADM_EINVAL;
+  hipLaunchKernelGGL(concat2_kernel, dim3(ew_grid(M * ((Ca + Cb) / 4))), dim3(256), 0, stream, da, Ca / 4, db, Cb / 4,
+                     const_cast<float*>(dy), M, scale_b, 1, static_cast<float*>(nullptr));
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
 
 extern "C" int adm_spatial_att_fwd(const float* att, int ldatt, const float* qk, const float* h, const float* xres,
                                    float* y, int B, int HW, int C, hipStream_t stream) {

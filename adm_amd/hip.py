@@ -101,7 +101,8 @@ _SIGS = {
     "adm_add": [P, P, P, L, P],
     "adm_add3": [P, P, P, P, P, L, P],
     "adm_copy_channels": [P, I, I, P, I, I, L, I, F, I, P],
-    "adm_copy_channels_amax": [P, I, I, P, I, I, L, I, F, I, P, P],
+    "adm_concat2": [P, I, P, I, P, L, F, P, P],
+    "adm_split2": [P, P, I, P, I, L, F, P],
     "adm_spatial_att_fwd": [P, I, P, P, P, P, I, I, I, P],
     "adm_spatial_att_bwd": [P, I, P, P, P, P, P, P, P, I, I, I, P],
     "adm_q_sample": [P, P, P, P, I, L, I, P],

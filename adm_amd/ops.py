@@ -1570,12 +1570,8 @@ class _Concat(torch.autograd.Function):
         y = _new((*a.shape[:-1], ca + cb), a)
         global _cat_amax_out
         _cat_amax_out = slot = _amax_slot(a) if (FP16X3 and H3_GEMM and BF16X6 and COMPUTE == "f32" and a.is_cuda) else None
-        if slot is not None:         # the concatenation feeds a block's 1x1 skip conv: the copies leave the bound of what they wrote
-            call("adm_copy_channels_amax", ptr(a), ca, 0, ptr(y), ca + cb, 0, M, ca, 1.0, 0, ptr(slot))
-            call("adm_copy_channels_amax", ptr(b), cb, 0, ptr(y), ca + cb, ca, M, cb, float(scale_b), 0, ptr(slot))
-        else:
-            call("adm_copy_channels", ptr(a), ca, 0, ptr(y), ca + cb, 0, M, ca, 1.0, 0)
-            call("adm_copy_channels", ptr(b), cb, 0, ptr(y), ca + cb, ca, M, cb, float(scale_b), 0)
+        # one launch for both halves; the concatenation feeds a block's 1x1 skip conv: the copy leaves the bound of what it wrote
+        call("adm_concat2", ptr(a), ca, ptr(b), cb, ptr(y), M, float(scale_b), ptr(slot))
         ctx.meta = (ca, cb, scale_b)
         return y
 
@@ -1586,8 +1582,7 @@ class _Concat(torch.autograd.Function):
         M = dy.numel() // (ca + cb)
         da = _new((*dy.shape[:-1], ca), dy)
         db = _new((*dy.shape[:-1], cb), dy)
-        call("adm_copy_channels", ptr(dy), ca + cb, 0, ptr(da), ca, 0, M, ca, 1.0, 0)
-        call("adm_copy_channels", ptr(dy), ca + cb, ca, ptr(db), cb, 0, M, cb, float(scale_b), 0)
+        call("adm_split2", ptr(dy), ptr(da), ca, ptr(db), cb, M, float(scale_b))
         bound = _get_amax(dy)            # max |da|, max |db| <= max |dy| (scale_b <= 1)
         if bound is not None:
             _reg_amax(da, bound)

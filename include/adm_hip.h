@@ -381,9 +381,10 @@ int adm_add3(const float* a, const float* b, const float* c, float* y, float* am
  * (torch.cat, :571, :578; `scale` carries uncond_unet_sd_3's skip-tuning ratio) */
 int adm_copy_channels(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
                       float scale, int acc, hipStream_t stream);
-/* ... that also raises the bound vector amax to the maximum of what it wrote */
-int adm_copy_channels_amax(const float* src, int lds, int src_off, float* dst, int ldd, int dst_off, long M, int C,
-                           float scale, int acc, float* amax, hipStream_t stream);
+/* torch.cat((a, scale_b * b), channel axis) of two NHWC tensors in ONE launch (uncond_unet.py:571; `scale_b` = uncond_unet_sd_3's
+ * skip-tuning ratio), amax (may be NULL) = bound vector raised to max |y|; adm_split2 = its adjoint (da = dy[:, :Ca], db = scale_b dy[:, Ca:]) */
+int adm_concat2(const float* a, int Ca, const float* b, int Cb, float* y, long M, float scale_b, float* amax, hipStream_t stream);
+int adm_split2(const float* dy, float* da, int Ca, float* db, int Cb, long M, float scale_b, hipStream_t stream);
 /* out[b,i] = a[b] * x[b,i] + s[b] * y[b,i]  (x may be NULL -> s*y only; x fp32 or fp64): the
  * single-decoder variants' D_y = (x - (sigma-1) D_x) / g(sigma)  (uncond_unet_sd.py:602) and its backward */
 int adm_axpby_b(const void* x, int x_is_f64, const float* y, const float* a, const float* s, long coef_bstride,
