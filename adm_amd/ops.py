@@ -319,7 +319,7 @@ def _wino2_operands(weight: torch.Tensor, ent: "_Packed", which: int):
     return getattr(ent, name)
 
 
-GEMM_X6_MIN_M = int(os.environ.get("ADM_GEMM_X6_MIN_M", "8192"))
+GEMM_X6_MIN_M = int(os.environ.get("ADM_GEMM_X6_MIN_M", "2048"))      # (8192 until round 3: the 4x4 level's 1x1 convs, +0.7 %)
 # The 1x1 WEIGHT gradient on the split-bf16 kernel (conv_wgrad_x6.hip MODE 1: four 16-pixel chunks in place of the four ex planes).
 # With the first version of that kernel it was no faster than the f32 direct kernel (65-103 vs 47-111 TFLOP/s per shape); on the
 # twelve-wave version (one plane per consumer wave, 64 x 64 tiles) it is: 84-126 vs 51-109 TFLOP/s on every 1x1 shape of the UNet

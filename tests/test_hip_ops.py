@@ -211,7 +211,7 @@ def test_conv_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, W, up):
                                                         (16, 768, 128, 24, False, True), (8, 32, 128, 32, False, False), (8, 128, 96, 32, False, True),
                                                         (8, 576, 192, 32, False, True), (8, 192, 576, 32, False, False)])
 def test_conv1x1_x6_forward_backward(ops, monkeypatch, B, cin, cout, H, qkv, with_res):
-    """1x1 convs with >= 8192 pixels run on conv_gemm_x6.hip (f32 products as six bf16 MFMAs on the exact three-term split): forward
+    """1x1 convs with >= 2048 pixels (GEMM_X6_MIN_M) run on conv_gemm_x6.hip (f32 products as six bf16 MFMAs on the exact three-term split): forward
     (bias, residual, the qkv row permutation), data gradient, and -- through the direct kernels -- weight / bias gradients, against
     F.conv2d on the CPU; ragged pixel counts; then the weights are changed in place and refreshed by repack_all()."""
     monkeypatch.setattr(ops, "BF16X6", True)
