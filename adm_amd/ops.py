@@ -1481,9 +1481,12 @@ def affine_group(emb, grp: AffineGroup):
 # ------------------------------------------------------------------------------------------------
 # attention core
 # ------------------------------------------------------------------------------------------------
+ATTN_H3 = os.environ.get("ADM_ATTN_H3", "1") != "0"      # attention forward on the fp16 split format where qkv came with a bound
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, heads):
+    def forward(ctx, qkv, heads, amax=None):
         qkv = _chk(qkv, "qkv")
         B, H, W, C3 = qkv.shape
         L = H * W
@@ -1491,8 +1494,12 @@ class _Attention(torch.autograd.Function):
             raise RuntimeError(f"qkv has {C3} channels, expected {heads * 192}")
         out = _new((B, H, W, heads * 64), qkv)
         lse = _new((B * heads, L), qkv)
-        with _Prof("attn", 4.0 * L * L * 64 * B * heads):
-            call("adm_attn_fwd", ptr(qkv), ptr(out), ptr(lse), B, L, heads)
+        h3 = amax is not None and ATTN_H3 and FP16X3 and COMPUTE == "f32" and L in (32, 64, 128, 256)
+        with _Prof("attnh3" if h3 else "attn", 4.0 * L * L * 64 * B * heads):
+            if h3:
+                call("adm_attn_fwd_h3", ptr(qkv), ptr(out), ptr(lse), ptr(amax), B, L, heads)
+            else:
+                call("adm_attn_fwd", ptr(qkv), ptr(out), ptr(lse), B, L, heads)
         ctx.save_for_backward(qkv, out, lse)
         ctx.heads = heads
         return out
@@ -1511,12 +1518,12 @@ class _Attention(torch.autograd.Function):
             else:
                 call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)
         _reg_amax(dqkv, slot_a)
-        return dqkv, None
+        return dqkv, None, None
 
 
 def attention(qkv, heads: int):
-    out = _Attention.apply(qkv, heads)
     a = getattr(qkv, "_adm_amax", None)
+    out = _Attention.apply(qkv, heads, a)
     if a is not None:
         out._adm_amax = a            # rows of softmax(q k^T) v are convex combinations of rows of v: |out| <= max |v| <= max |qkv|
     return out

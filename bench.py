@@ -314,9 +314,9 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         # wino2x6: f32 products carried by SIX bf16 MFMAs (exact three-term split): its MFMA pipe executes 6 x 4/9 of the algorithmic
         # flops as bf16 flops and is priced against the bf16 peak
-        PEAKS = {"gemmh3": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2h3": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmh3": PEAK_BF16_MFMA_TFLOPS, "wino2h3": PEAK_BF16_MFMA_TFLOPS, "wino2x6": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2x6": PEAK_BF16_MFMA_TFLOPS, "gemmx6": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmx6": PEAK_BF16_MFMA_TFLOPS}
-        PMC_CLASS = {"gemmh3": "gemm_x6", "wgrad_wino2h3": "wgrad_x6", "wgrad_gemmh3": "wgrad_x6", "wino2h3": "wino2d_x6", "wino2x6": "wino2d_x6", "wino2": "wino2d", "wgrad_wino2": "wgrad_wino2d", "wgrad_wino2x6": "wgrad_x6", "gemmx6": "gemm_x6", "wgrad_gemmx6": "wgrad_x6", "attn": "attn"}
-        EXEC = {"gemmh3": 3.0, "wgrad_wino2h3": 3.0 * 4.0 / 9.0, "wgrad_gemmh3": 3.0, "wino2h3": 3.0 * 4.0 / 9.0, "wino2x6": 6.0 * 4.0 / 9.0, "wgrad_wino2x6": 6.0 * 4.0 / 9.0, "gemmx6": 6.0, "wgrad_gemmx6": 6.0, "wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino2": 4.0 / 9.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
+        PEAKS = {"attnh3": PEAK_BF16_MFMA_TFLOPS, "gemmh3": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2h3": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmh3": PEAK_BF16_MFMA_TFLOPS, "wino2h3": PEAK_BF16_MFMA_TFLOPS, "wino2x6": PEAK_BF16_MFMA_TFLOPS, "wgrad_wino2x6": PEAK_BF16_MFMA_TFLOPS, "gemmx6": PEAK_BF16_MFMA_TFLOPS, "wgrad_gemmx6": PEAK_BF16_MFMA_TFLOPS}
+        PMC_CLASS = {"attnh3": "attn", "gemmh3": "gemm_x6", "wgrad_wino2h3": "wgrad_x6", "wgrad_gemmh3": "wgrad_x6", "wino2h3": "wino2d_x6", "wino2x6": "wino2d_x6", "wino2": "wino2d", "wgrad_wino2": "wgrad_wino2d", "wgrad_wino2x6": "wgrad_x6", "gemmx6": "gemm_x6", "wgrad_gemmx6": "wgrad_x6", "attn": "attn"}
+        EXEC = {"attnh3": 3.0, "gemmh3": 3.0, "wgrad_wino2h3": 3.0 * 4.0 / 9.0, "wgrad_gemmh3": 3.0, "wino2h3": 3.0 * 4.0 / 9.0, "wino2x6": 6.0 * 4.0 / 9.0, "wgrad_wino2x6": 6.0 * 4.0 / 9.0, "gemmx6": 6.0, "wgrad_gemmx6": 6.0, "wino2": 4.0 / 9.0, "wino": 2.0 / 3.0, "wgrad_wino2": 4.0 / 9.0, "wgrad_wino": 2.0 / 3.0, "attn": 1.0, "igemm": 1.0, "wgrad": 1.0}
         NAMES = {"wino2h3": "wino2d_x6_kernel<1> (3x3 conv forward, 2-D Winograd F(2x2,3x3); f32 products as THREE fp16 MFMAs on a two-term "
                             "round-to-nearest fp16 split scaled by the operand's max (written by the GroupNorm kernel), f32 accumulate)",
                  "wino2x6": "wino2d_x6_kernel<0> (3x3 conv forward + data-gradient, 2-D Winograd F(2x2,3x3); f32 products as six bf16 MFMAs "
@@ -336,6 +336,7 @@ def main():
                  "wgrad_wino2": "wgrad_wino_kernel<2> (3x3 weight gradient, 2-D Winograd F(3x3,2x2))",
                  "wgrad_wino": "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3,2): fused-upsample layers)",
                  "wgrad": "wgrad_f32_kernel (direct: 1x1 / Linear / small-map layers)",
+                 "attnh3": "attn_fwd_h3_kernel (attention forward, both products as three fp16 MFMAs per f32 product; bound of qkv from the qkv conv's epilogue)",
                  "attn": "attn_fwd / attn_bwd_dq / attn_bwd_dkv"}
 
         def mfma_entry(kind):
@@ -386,7 +387,7 @@ def main():
                      "convention": "achieved = EXECUTED MFMA flops / kernel time (HIP events around every launch of one profiled step); "
                              "frac = achieved / peak.  Winograd executes 4/9 (2-D F(2x2,3x3)) or 2/3 (1-D F(2,3)) of the direct convolution's flops: "
                              "`algorithmic` is the direct-convolution rate (SURVEY 8d's 213.9 GFLOP/image figures)."})
-        for kind, key in (("wino2x6", "wino2d_x6"), ("wino2h3", "wino2d_h3"), ("wino2", "wino2d_f32"), ("wino", "wino_1d"), ("igemm", "igemm_direct"), ("gemmx6", "gemm_x6"), ("gemmh3", "gemm_h3"), ("wgrad_wino2x6", "wgrad_x6"), ("wgrad_wino2h3", "wgrad_h3"), ("wgrad_gemmx6", "wgrad_gemm_x6"), ("wgrad_gemmh3", "wgrad_gemm_h3"), ("wgrad_wino2", "wgrad_wino2d"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention")):
+        for kind, key in (("wino2x6", "wino2d_x6"), ("wino2h3", "wino2d_h3"), ("wino2", "wino2d_f32"), ("wino", "wino_1d"), ("igemm", "igemm_direct"), ("gemmx6", "gemm_x6"), ("gemmh3", "gemm_h3"), ("wgrad_wino2x6", "wgrad_x6"), ("wgrad_wino2h3", "wgrad_h3"), ("wgrad_gemmx6", "wgrad_gemm_x6"), ("wgrad_gemmh3", "wgrad_gemm_h3"), ("wgrad_wino2", "wgrad_wino2d"), ("wgrad_wino", "wgrad_wino"), ("wgrad", "wgrad"), ("attn", "attention"), ("attnh3", "attention_fwd_h3")):
             if kind in by and kind != dom_kind:
                 roof[key] = mfma_entry(kind)
         # whole step against the MFMA roof: every GEMM-shaped launch of the profiled step

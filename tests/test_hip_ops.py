@@ -463,6 +463,39 @@ def test_attention(ops, L, heads):
     close(from_packed(nchw(qd.grad)), qkv.grad)
 
 
+@pytest.mark.parametrize("L,heads,scale", [(256, 6, 1.5), (64, 2, 1.5), (256, 1, 6.0), (1024, 1, 1.5)])
+def test_attention_forward_fp16_format(ops, monkeypatch, L, heads, scale):
+    """The attention forward on the fp16 split format (attention_h3.hip: three fp16 MFMAs per f32 product in both matrix products; V
+    transposed in LDS with the keys in the accumulator layout's order) against the oracle's attention core and against an fp64
+    softmax(q k^T / 8) v: peaked softmaxes (scale 6: logits up to a few hundred), exact and 8x loose bounds of |qkv|; error at the f32 kernel's level; the
+    backward (f32 kernels on the saved forward) still matches; L = 1024 has no fp16 kernel and must fall back."""
+    B, h, C = 2, int(math.isqrt(L)), 64 * heads
+    qkv = fill.hash_tensor((B, 3 * C, h, h), f"attnh{L}.{heads}", scale).requires_grad_(True)
+    a_ref = unet_ref.attention_core(qkv, heads)
+    gy = fill.hash_tensor(a_ref.shape, f"agh{L}", 1.0)
+    (a_ref * gy).sum().backward()
+    to_packed = lambda t: t.reshape(B, heads, 64, 3, h, h).permute(0, 1, 3, 2, 4, 5).reshape(B, 3 * C, h, h)
+    from_packed = lambda t: t.reshape(B, heads, 3, 64, h, h).permute(0, 1, 3, 2, 4, 5).reshape(B, 3 * C, h, h)
+    q64 = qkv.detach().double().reshape(B * heads, 64, 3, L)
+    w64 = torch.softmax(torch.einsum("ncq,nck->nqk", q64[:, :, 0], q64[:, :, 1] / 8.0), dim=2)
+    a64 = torch.einsum("nqk,nck->ncq", w64, q64[:, :, 2]).reshape(B, C, h, h)
+    errs = {}
+    for mode, loose in (("f32", 1.0), ("h3", 1.0), ("h3", 8.0)):
+        monkeypatch.setattr(ops, "ATTN_H3", mode == "h3")
+        qd = nhwc(to_packed(qkv.detach())).requires_grad_(True)
+        qd._adm_amax = _amax(qd) * loose
+        monkeypatch.setattr(ops, "PROFILE", [])
+        a = ops.attention(qd, heads)
+        kinds = [k[0] for k in ops.PROFILE]
+        assert kinds == (["attnh3"] if (mode == "h3" and L <= 256) else ["attn"]), kinds
+        close(nchw(a), a_ref)
+        errs[(mode, loose)] = float((nchw(a).double() - a64).abs().max()) / float(a64.abs().max())
+        (a * nhwc(gy)).sum().backward()
+        close(from_packed(nchw(qd.grad)), qkv.grad)
+    print(f"attention forward error / max|out| vs fp64: f32 MFMA {errs[('f32', 1.0)]:.2e}, fp16 format {errs[('h3', 1.0)]:.2e} (bound x 8: {errs[('h3', 8.0)]:.2e})")
+    assert errs[("h3", 1.0)] <= max(3.0 * errs[("f32", 1.0)], 5e-7) and errs[("h3", 8.0)] <= max(4.0 * errs[("f32", 1.0)], 1e-6), errs
+
+
 def test_resample_concat_silu_posemb(ops):
     x = fill.hash_tensor((2, 64, 8, 8), "rs", 1.0).requires_grad_(True)
     gy_d = fill.hash_tensor((2, 64, 4, 4), "rsd", 1.0)
