@@ -195,7 +195,267 @@ int launch_fwd_h3(const float* qkv, float* out, float* lse, const float* amax, i
   return ADM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward on the same format.  Both kernels keep attention.hip's orientations (queries on lanes for dQ, keys on lanes for dK / dV: no
+// score tile is transposed or summed with atomics); what changes is where the operands of the K = 16 MFMAs come from:
+//   * products whose reduction index is d (S, dP): one side is a ROW image [term][row][64] in LDS, the other a register fragment;
+//   * products whose reduction index is the accumulator-row index of a score tile (dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS): the
+//     score-side operand is the tile as it stands, the other side a TRANSPOSED image [term][d][row'] with the rows of every group of
+//     16 in the accumulator layout's order (ah_pos16), as V^T in the forward.
+// LDS holds 128 rows of the other side at a time (three / four images: 108 / 144 KB); dS gets a static scale from the bound
+// |dS| <= |dP| + |delta| <= 128 max|dO| max|qkv| (loose by orders of magnitude: costs nothing but the smallest values' last bits).
+__device__ __forceinline__ f32x16 ah_mfma3(const ah_u32x4 a0, const ah_u32x4 a1, const ah_u32x4 b0, const ah_u32x4 b1, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ah_f16x8, a0), __builtin_bit_cast(ah_f16x8, b1), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ah_f16x8, a1), __builtin_bit_cast(ah_f16x8, b0), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ah_f16x8, a0), __builtin_bit_cast(ah_f16x8, b0), c, 0, 0, 0);
+}
+// dst[term][row][AH_KROW] <- two-term split of scale * src[row][0..63] (rows at a stride of `rs` floats), CH rows
+__device__ __forceinline__ void ah_fill_rows(unsigned short* dst, int CH, const float* src, long rs, float scale, int tid, int nthreads) {
+  for (int i = tid; i < CH * 16; i += nthreads) {
+    const int row = i >> 4, c4 = i & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)row * rs + c4 * 4);
+    unsigned t0[2], t1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float x0 = v[2 * j] * scale, x1 = v[2 * j + 1] * scale;
+      const _Float16 h00 = (_Float16)x0, h01 = (_Float16)x1;
+      t0[j] = __builtin_bit_cast(unsigned, ah_f16x2{h00, h01});
+      t1[j] = __builtin_bit_cast(unsigned, ah_f16x2{(_Float16)(x0 - (float)h00), (_Float16)(x1 - (float)h01)});
+    }
+    *reinterpret_cast<uint2*>(dst + row * AH_KROW + c4 * 4) = make_uint2(t0[0], t0[1]);
+    *reinterpret_cast<uint2*>(dst + (CH + row) * AH_KROW + c4 * 4) = make_uint2(t1[0], t1[1]);
+  }
+}
+// dst[term][d][CH + 8] <- the same values transposed, rows permuted within groups of 16 (ah_pos16)
+__device__ __forceinline__ void ah_fill_transposed(unsigned short* dst, int CH, const float* src, long rs, float scale, int tid, int nthreads) {
+  const int VROW = CH + 8;
+  for (int i = tid; i < (CH / 2) * 16; i += nthreads) {
+    const int kp = i >> 4, c4 = i & 15;
+    const int grp = kp >> 3, p0 = (kp & 7) * 2;
+    const int r0 = grp * 16 + ((p0 & 7) & 3) + 8 * ((p0 & 7) >> 2) + 4 * (p0 >> 3);      // rows r0, r0 + 1 sit at positions p0, p0 + 1
+    const f32x4 va = *reinterpret_cast<const f32x4*>(src + (long)r0 * rs + c4 * 4);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(src + (long)(r0 + 1) * rs + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = va[j] * scale, x1 = vb[j] * scale;
+      const _Float16 h00 = (_Float16)x0, h01 = (_Float16)x1;
+      const int d = c4 * 4 + j;
+      *reinterpret_cast<unsigned*>(dst + d * VROW + grp * 16 + p0) = __builtin_bit_cast(unsigned, ah_f16x2{h00, h01});
+      *reinterpret_cast<unsigned*>(dst + (64 + d) * VROW + grp * 16 + p0) =
+          __builtin_bit_cast(unsigned, ah_f16x2{(_Float16)(x0 - (float)h00), (_Float16)(x1 - (float)h01)});
+    }
+  }
+}
+// a lane's fragment of its own row: 4 chunks of 16 d, 8 consecutive d per lane half
+__device__ __forceinline__ void ah_row_frag(const float* row, int lh, float scale, ah_u32x4 (&t0)[4], ah_u32x4 (&t1)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(row + 16 * c + 8 * lh);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(row + 16 * c + 8 * lh + 4);
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    ah_split8(v, scale, t0[c], t1[c]);
+  }
+}
+// 32 x 32 tile: rows of a row image (A operand, reduction over d) times the lane's fragment
+__device__ __forceinline__ f32x16 ah_rows_times_frag(const unsigned short* img, int CH, int row0, const ah_u32x4 (&f0)[4], const ah_u32x4 (&f1)[4],
+                                                     int lr, int lh) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const unsigned short* rp = img + (row0 + lr) * AH_KROW + 8 * lh;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    acc = ah_mfma3(*reinterpret_cast<const ah_u32x4*>(rp + 16 * c), *reinterpret_cast<const ah_u32x4*>(rp + CH * AH_KROW + 16 * c), f0[c], f1[c], acc);
+  return acc;
+}
+// o^T[d][lane] += sum over the tile's 32 rows of timg[d][row] * t[row] (t in the accumulator layout, scaled by `scale` for the split)
+__device__ __forceinline__ void ah_accum_T(f32x16 (&o)[2], const unsigned short* timg, int CH, int row0, const f32x16& t, float scale, int lr, int lh) {
+  const int VROW = CH + 8;
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const float tv[8] = {t[8 * sl], t[8 * sl + 1], t[8 * sl + 2], t[8 * sl + 3], t[8 * sl + 4], t[8 * sl + 5], t[8 * sl + 6], t[8 * sl + 7]};
+    ah_u32x4 b0, b1;
+    ah_split8(tv, scale, b0, b1);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const unsigned short* vp = timg + (db * 32 + lr) * VROW + row0 + 16 * sl + 8 * lh;
+      o[db] = ah_mfma3(*reinterpret_cast<const ah_u32x4*>(vp), *reinterpret_cast<const ah_u32x4*>(vp + 64 * VROW), b0, b1, o[db]);
+    }
+  }
+}
+__device__ __forceinline__ void ah_store_T(const f32x16 (&o)[2], float* rowptr, int lh, float scale, float& am) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 v = {o[db][4 * q4] * scale, o[db][4 * q4 + 1] * scale, o[db][4 * q4 + 2] * scale, o[db][4 * q4 + 3] * scale};
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      *reinterpret_cast<f32x4*>(rowptr + db * 32 + 8 * q4 + 4 * lh) = v;
+    }
+}
+
+// backward, part 1: queries on lanes.  dQ^T = K^T dS^T / 8, delta[q] = sum_d dO O
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_h3_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                                   const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                   float* __restrict__ dqkv, float* __restrict__ delta, int L, int heads,
+                                                                   const float* __restrict__ amax_qkv, const float* __restrict__ amax_g,
+                                                                   float* __restrict__ amax_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smh[];
+  constexpr int CH = NW >= 4 ? 128 : 32 * NW;        // keys in LDS at a time
+  unsigned short* Kh = smh;                          // [2][CH][AH_KROW]
+  unsigned short* Vh = Kh + 2 * CH * AH_KROW;
+  unsigned short* Kt = Vh + 2 * CH * AH_KROW;        // [2][64][CH + 8]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const long rs = (long)heads * 192, ro = (long)heads * 64;
+  const float* base = qkv + (long)b * L * rs + h * 192;
+  const float aq = adm_amax_read(amax_qkv), ag = adm_amax_read(amax_g);
+  const float sc = ah_scale(aq), sg = ah_scale(ag), sd = ah_scale(128.f * aq * ag);
+  const int q = wid * 32 + lr;
+  ah_u32x4 q0[4], q1[4], g0[4], g1[4];
+  ah_row_frag(base + (long)q * rs, lh, sc * 0.125f, q0, q1);
+  const float* grow = dout + ((long)b * L + q) * ro + h * 64;
+  const float* orow = out + ((long)b * L + q) * ro + h * 64;
+  ah_row_frag(grow, lh, sg, g0, g1);
+  float dl = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(grow + 16 * c + 8 * lh + 4 * hh);
+      const f32x4 ov = *reinterpret_cast<const f32x4*>(orow + 16 * c + 8 * lh + 4 * hh);
+      dl += gv[0] * ov[0] + gv[1] * ov[1] + gv[2] * ov[2] + gv[3] * ov[3];
+    }
+  dl += __shfl_xor(dl, 32, 64);
+  const float ls = lse[((long)b * heads + h) * L + q];
+  if (lh == 0) delta[((long)b * heads + h) * L + q] = dl;
+  const float inv_s = 1.f / (sc * sc), inv_g = 1.f / (sc * sg);
+  f32x16 dq[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+#pragma unroll 1
+  for (int k0 = 0; k0 < L; k0 += CH) {
+    __syncthreads();
+    ah_fill_rows(Kh, CH, base + (long)k0 * rs + 64, rs, sc, tid, 64 * NW);
+    ah_fill_rows(Vh, CH, base + (long)k0 * rs + 128, rs, sc, tid, 64 * NW);
+    ah_fill_transposed(Kt, CH, base + (long)k0 * rs + 64, rs, sc, tid, 64 * NW);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < CH / 32; ++kt) {
+      f32x16 s = ah_rows_times_frag(Kh, CH, kt * 32, q0, q1, lr, lh);
+      const f32x16 dp = ah_rows_times_frag(Vh, CH, kt * 32, g0, g1, lr, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __expf(s[r] * inv_s - ls) * (dp[r] * inv_g - dl);      // dS^T[key][q]
+      ah_accum_T(dq, Kt, CH, kt * 32, s, sd, lr, lh);
+    }
+  }
+  float am = 0.f;
+  ah_store_T(dq, dqkv + ((long)b * L + q) * rs + h * 192, lh, 0.125f / (sc * sd), am);
+  adm_amax_commit(am, amax_out);
+}
+
+// backward, part 2: keys on lanes.  dV^T = dO^T P, dK^T = Q^T dS / 8
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_h3_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                    float* __restrict__ dqkv, int L, int heads,
+                                                                    const float* __restrict__ amax_qkv, const float* __restrict__ amax_g,
+                                                                    float* __restrict__ amax_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smh[];
+  constexpr int CH = NW >= 4 ? 128 : 32 * NW;        // queries in LDS at a time
+  unsigned short* Qh = smh;                          // [2][CH][AH_KROW]
+  unsigned short* Gh = Qh + 2 * CH * AH_KROW;        // dO rows
+  unsigned short* Qt = Gh + 2 * CH * AH_KROW;        // [2][64][CH + 8]
+  unsigned short* Gt = Qt + 2 * 64 * (CH + 8);
+  float* Ls = reinterpret_cast<float*>(Gt + 2 * 64 * (CH + 8));      // lse[CH] | delta[CH]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const long rs = (long)heads * 192, ro = (long)heads * 64;
+  const float* base = qkv + (long)b * L * rs + h * 192;
+  const float aq = adm_amax_read(amax_qkv), ag = adm_amax_read(amax_g);
+  const float sc = ah_scale(aq), sg = ah_scale(ag), sd = ah_scale(128.f * aq * ag);
+  const int key = wid * 32 + lr;
+  ah_u32x4 k0f[4], k1f[4], v0f[4], v1f[4];
+  ah_row_frag(base + (long)key * rs + 64, lh, sc * 0.125f, k0f, k1f);
+  ah_row_frag(base + (long)key * rs + 128, lh, sc, v0f, v1f);
+  const float inv_s = 1.f / (sc * sc), inv_g = 1.f / (sg * sc);
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+#pragma unroll 1
+  for (int q0 = 0; q0 < L; q0 += CH) {
+    __syncthreads();
+    const float* gsrc = dout + ((long)b * L + q0) * ro + h * 64;
+    ah_fill_rows(Qh, CH, base + (long)q0 * rs, rs, sc, tid, 64 * NW);
+    ah_fill_rows(Gh, CH, gsrc, ro, sg, tid, 64 * NW);
+    ah_fill_transposed(Qt, CH, base + (long)q0 * rs, rs, sc, tid, 64 * NW);
+    ah_fill_transposed(Gt, CH, gsrc, ro, sg, tid, 64 * NW);
+    for (int i = tid; i < CH; i += 64 * NW) {
+      Ls[i] = lse[((long)b * heads + h) * L + q0 + i];
+      Ls[CH + i] = delta[((long)b * heads + h) * L + q0 + i];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int qt = 0; qt < CH / 32; ++qt) {
+      f32x16 s = ah_rows_times_frag(Qh, CH, qt * 32, k0f, k1f, lr, lh);       // S[q][key] (already / 8)
+      const f32x16 dp = ah_rows_times_frag(Gh, CH, qt * 32, v0f, v1f, lr, lh);   // dP[q][key]
+      f32x16 ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = qt * 32 + ah_acc_row(r, lh);
+        const float p = __expf(s[r] * inv_s - Ls[qq]);
+        s[r] = p;
+        ds[r] = p * (dp[r] * inv_g - Ls[CH + qq]);
+      }
+      ah_accum_T(dv, Gt, CH, qt * 32, s, 16384.f, lr, lh);
+      ah_accum_T(dk, Qt, CH, qt * 32, ds, sd, lr, lh);
+    }
+  }
+  float am = 0.f;
+  float* orow = dqkv + ((long)b * L + key) * rs + h * 192;
+  ah_store_T(dk, orow + 64, lh, 0.125f / (sc * sd), am);
+  ah_store_T(dv, orow + 128, lh, 1.f / (sg * 16384.f), am);
+  adm_amax_commit(am, amax_out);
+}
+
+template <int NW>
+int launch_bwd_h3(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta, const float* amax_qkv,
+                  const float* amax_g, float* amax_out, int B, int L, int heads, hipStream_t st) {
+  constexpr int CH = NW >= 4 ? 128 : 32 * NW;
+  constexpr int smem_dq = (4 * CH * AH_KROW + 2 * 64 * (CH + 8)) * (int)sizeof(unsigned short);
+  constexpr int smem_dkv = (4 * CH * AH_KROW + 4 * 64 * (CH + 8)) * (int)sizeof(unsigned short) + 2 * CH * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_h3_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_h3_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv) != hipSuccess)
+      return ADM_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dq_h3_kernel<NW>), dim3(B * heads), dim3(64 * NW), smem_dq, st, qkv, out, dout, lse, dqkv, delta, L, heads,
+                     amax_qkv, amax_g, amax_out);
+  hipLaunchKernelGGL((attn_bwd_dkv_h3_kernel<NW>), dim3(B * heads), dim3(64 * NW), smem_dkv, st, qkv, dout, lse, delta, dqkv, L, heads,
+                     amax_qkv, amax_g, amax_out);
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+
 }  // namespace
+
+// adm_attn_bwd on the fp16 split format: amax_qkv / amax_dout = bound vectors of |qkv| and |dout|; amax_dqkv (may be NULL) = bound vector
+// raised to max |dqkv|.  L in {32, 64, 128, 256} (ADM_EINVAL otherwise); delta [B*heads][L] scratch as in adm_attn_bwd.
+extern "C" int adm_attn_bwd_h3(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
+                               const float* amax_qkv, const float* amax_dout, float* amax_dqkv, int B, int L, int heads, hipStream_t stream) {
+  if (!qkv || !out || !dout || !lse || !dqkv || !delta || !amax_qkv || !amax_dout || B <= 0 || heads <= 0) return ADM_EINVAL;
+  if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout) & 15) return ADM_EINVAL;
+  switch (L) {
+    case 32: return launch_bwd_h3<1>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
+    case 64: return launch_bwd_h3<2>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
+    case 128: return launch_bwd_h3<4>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
+    case 256: return launch_bwd_h3<8>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
+    default: return ADM_EINVAL;
+  }
+}
 
 // adm_attn_fwd on the fp16 split format: amax = bound vector (include/adm_hip.h) of |qkv| (the qkv conv's epilogue wrote it).  L in
 // {32, 64, 128, 256} only (ADM_EINVAL otherwise: the caller stays on adm_attn_fwd); same outputs to f32 rounding.

@@ -91,6 +91,7 @@ _SIGS = {
     "adm_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "adm_attn_bwd_amax": [P, P, P, P, P, P, P, I, I, I, P],
     "adm_attn_fwd_h3": [P, P, P, P, I, I, I, P],
+    "adm_attn_bwd_h3": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "adm_resample2x": [P, P, I, I, I, I, I, F, I, P],
     "adm_nchw_to_nhwc": [P, I, P, L, P, I, I, I, I, P],
     "adm_precond_out": [P, I, P, I, P, P, L, P, I, I, I, P],

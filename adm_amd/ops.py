@@ -1080,9 +1080,11 @@ class _Conv(torch.autograd.Function):
                     wsk = _new((sk * B * Ho * Wo * cip,), dy) if sk > 1 else None
                     call("adm_conv_fwd_wino2d_h3", ptr(dy), ptr(_h3_operands(weight, pk, 1)), None, None, ptr(dxf), ptr(wsk),
                          0 if wsk is None else wsk.numel(), B, Ho, Wo, cop, cop, cip, cip, cip, cip, ptr(amax_dy), H3_WSCALE, 0)
-                elif g6h:
+                elif g6h:       # (the epilogue leaves max |dx|: the attention backward behind a proj conv runs on the fp16 format)
+                    slot_dx = _amax_slot(dy)
                     call("adm_gemm_x6_h3", ptr(dy), ptr(_gemm_h3_operand(pk, 1)), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
-                         cip, cip, ptr(amax_g), H3_WSCALE, None)
+                         cip, cip, ptr(amax_g), H3_WSCALE, ptr(slot_dx))
+                    _reg_amax(dxf, slot_dx)
                 elif g6:
                     call("adm_gemm_x6", ptr(dy), ptr(_gemm_x6_operand(pk, 1)), None, None, ptr(dxf), B * Ho * Wo, cop, cop, cip, cip,
                          cip, cip)
@@ -1482,6 +1484,7 @@ def affine_group(emb, grp: AffineGroup):
 # attention core
 # ------------------------------------------------------------------------------------------------
 ATTN_H3 = os.environ.get("ADM_ATTN_H3", "1") != "0"      # attention forward on the fp16 split format where qkv came with a bound
+ATTN_H3_BWD = os.environ.get("ADM_ATTN_H3_BWD", "1") != "0"      # ... and the backward, where dout came with one too
 
 
 class _Attention(torch.autograd.Function):
@@ -1502,6 +1505,7 @@ class _Attention(torch.autograd.Function):
                 call("adm_attn_fwd", ptr(qkv), ptr(out), ptr(lse), B, L, heads)
         ctx.save_for_backward(qkv, out, lse)
         ctx.heads = heads
+        ctx.amax_qkv = amax if h3 else None
         return out
 
     @staticmethod
@@ -1512,8 +1516,12 @@ class _Attention(torch.autograd.Function):
         dqkv = _like(qkv)
         delta = _like(lse)
         slot_a = _amax_slot(qkv) if (FP16X3 and H3_GEMM and BF16X6 and COMPUTE == "f32") else None     # max |dqkv| for the qkv conv's gradients
-        with _Prof("attn", 10.0 * (H * W) ** 2 * 64 * B * ctx.heads):
-            if slot_a is not None:
+        amax_g = _get_amax(dout) if (ctx.amax_qkv is not None and ATTN_H3_BWD) else None
+        with _Prof("attnh3" if amax_g is not None else "attn", 10.0 * (H * W) ** 2 * 64 * B * ctx.heads):
+            if amax_g is not None:      # both bounds at hand: the fp16 split format (attention_h3.hip)
+                call("adm_attn_bwd_h3", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ptr(ctx.amax_qkv), ptr(amax_g),
+                     ptr(slot_a), B, H * W, ctx.heads)
+            elif slot_a is not None:
                 call("adm_attn_bwd_amax", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), ptr(slot_a), B, H * W, ctx.heads)
             else:
                 call("adm_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, H * W, ctx.heads)

@@ -479,7 +479,12 @@ def test_attention_forward_fp16_format(ops, monkeypatch, L, heads, scale):
     q64 = qkv.detach().double().reshape(B * heads, 64, 3, L)
     w64 = torch.softmax(torch.einsum("ncq,nck->nqk", q64[:, :, 0], q64[:, :, 1] / 8.0), dim=2)
     a64 = torch.einsum("nqk,nck->ncq", w64, q64[:, :, 2]).reshape(B, C, h, h)
-    errs = {}
+    q64g = qkv.detach().double().clone().requires_grad_(True)
+    qq = q64g.reshape(B * heads, 64, 3, L)
+    wg = torch.softmax(torch.einsum("ncq,nck->nqk", qq[:, :, 0], qq[:, :, 1] / 8.0), dim=2)
+    (torch.einsum("nqk,nck->ncq", wg, qq[:, :, 2]).reshape(B, C, h, h) * gy.double()).sum().backward()
+    g64 = q64g.grad
+    errs, gerr = {}, {}
     for mode, loose in (("f32", 1.0), ("h3", 1.0), ("h3", 8.0)):
         monkeypatch.setattr(ops, "ATTN_H3", mode == "h3")
         qd = nhwc(to_packed(qkv.detach())).requires_grad_(True)
@@ -490,10 +495,19 @@ def test_attention_forward_fp16_format(ops, monkeypatch, L, heads, scale):
         assert kinds == (["attnh3"] if (mode == "h3" and L <= 256) else ["attn"]), kinds
         close(nchw(a), a_ref)
         errs[(mode, loose)] = float((nchw(a).double() - a64).abs().max()) / float(a64.abs().max())
-        (a * nhwc(gy)).sum().backward()
+        # the backward on the same format needs the bound of dout as well (in the model: the proj conv's data gradient leaves it)
+        gyd = nhwc(gy)
+        monkeypatch.setattr(ops, "_get_amax", (lambda t, loose=loose: _amax(t) * loose) if mode == "h3" else (lambda t: None))
+        monkeypatch.setattr(ops, "PROFILE", [])
+        (a * gyd).sum().backward()
+        kinds = [k[0] for k in ops.PROFILE]
+        assert kinds == (["attnh3"] if (mode == "h3" and L <= 256) else ["attn"]), kinds
         close(from_packed(nchw(qd.grad)), qkv.grad)
+        gerr[(mode, loose)] = float((from_packed(nchw(qd.grad)).double() - g64).abs().max()) / float(g64.abs().max())
     print(f"attention forward error / max|out| vs fp64: f32 MFMA {errs[('f32', 1.0)]:.2e}, fp16 format {errs[('h3', 1.0)]:.2e} (bound x 8: {errs[('h3', 8.0)]:.2e})")
     assert errs[("h3", 1.0)] <= max(3.0 * errs[("f32", 1.0)], 5e-7) and errs[("h3", 8.0)] <= max(4.0 * errs[("f32", 1.0)], 1e-6), errs
+    print(f"attention backward error / max|dqkv| vs fp64: f32 MFMA {gerr[('f32', 1.0)]:.2e}, fp16 format {gerr[('h3', 1.0)]:.2e} (bounds x 8: {gerr[('h3', 8.0)]:.2e})")
+    assert gerr[("h3", 1.0)] <= max(3.0 * gerr[("f32", 1.0)], 1e-6) and gerr[("h3", 8.0)] <= max(4.0 * gerr[("f32", 1.0)], 2e-6), gerr
 
 
 def test_resample_concat_silu_posemb(ops):
