@@ -226,24 +226,34 @@ __device__ __forceinline__ void ah_fill_rows(unsigned short* dst, int CH, const 
     *reinterpret_cast<uint2*>(dst + (CH + row) * AH_KROW + c4 * 4) = make_uint2(t1[0], t1[1]);
   }
 }
-// dst[term][d][CH + 8] <- the same values transposed, rows permuted within groups of 16 (ah_pos16)
-__device__ __forceinline__ void ah_fill_transposed(unsigned short* dst, int CH, const float* src, long rs, float scale, int tid, int nthreads) {
+// both images of one tensor from ONE pass over its rows (the dkv kernel needs Q and dO in both layouts, the dq kernel K)
+__device__ __forceinline__ void ah_fill_both(unsigned short* rimg, unsigned short* timg, int CH, const float* src, long rs, float scale,
+                                             int tid, int nthreads) {
   const int VROW = CH + 8;
   for (int i = tid; i < (CH / 2) * 16; i += nthreads) {
     const int kp = i >> 4, c4 = i & 15;
     const int grp = kp >> 3, p0 = (kp & 7) * 2;
-    const int r0 = grp * 16 + ((p0 & 7) & 3) + 8 * ((p0 & 7) >> 2) + 4 * (p0 >> 3);      // rows r0, r0 + 1 sit at positions p0, p0 + 1
+    const int r0 = grp * 16 + ((p0 & 7) & 3) + 8 * ((p0 & 7) >> 2) + 4 * (p0 >> 3);
     const f32x4 va = *reinterpret_cast<const f32x4*>(src + (long)r0 * rs + c4 * 4);
     const f32x4 vb = *reinterpret_cast<const f32x4*>(src + (long)(r0 + 1) * rs + c4 * 4);
+    _Float16 a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float x0 = va[j] * scale, x1 = vb[j] * scale;
-      const _Float16 h00 = (_Float16)x0, h01 = (_Float16)x1;
+      a0[j] = (_Float16)x0; a1[j] = (_Float16)(x0 - (float)a0[j]);
+      b0[j] = (_Float16)x1; b1[j] = (_Float16)(x1 - (float)b0[j]);
       const int d = c4 * 4 + j;
-      *reinterpret_cast<unsigned*>(dst + d * VROW + grp * 16 + p0) = __builtin_bit_cast(unsigned, ah_f16x2{h00, h01});
-      *reinterpret_cast<unsigned*>(dst + (64 + d) * VROW + grp * 16 + p0) =
-          __builtin_bit_cast(unsigned, ah_f16x2{(_Float16)(x0 - (float)h00), (_Float16)(x1 - (float)h01)});
+      *reinterpret_cast<unsigned*>(timg + d * VROW + grp * 16 + p0) = __builtin_bit_cast(unsigned, ah_f16x2{a0[j], b0[j]});
+      *reinterpret_cast<unsigned*>(timg + (64 + d) * VROW + grp * 16 + p0) = __builtin_bit_cast(unsigned, ah_f16x2{a1[j], b1[j]});
     }
+    *reinterpret_cast<uint2*>(rimg + r0 * AH_KROW + c4 * 4) =
+        make_uint2(__builtin_bit_cast(unsigned, ah_f16x2{a0[0], a0[1]}), __builtin_bit_cast(unsigned, ah_f16x2{a0[2], a0[3]}));
+    *reinterpret_cast<uint2*>(rimg + (CH + r0) * AH_KROW + c4 * 4) =
+        make_uint2(__builtin_bit_cast(unsigned, ah_f16x2{a1[0], a1[1]}), __builtin_bit_cast(unsigned, ah_f16x2{a1[2], a1[3]}));
+    *reinterpret_cast<uint2*>(rimg + (r0 + 1) * AH_KROW + c4 * 4) =
+        make_uint2(__builtin_bit_cast(unsigned, ah_f16x2{b0[0], b0[1]}), __builtin_bit_cast(unsigned, ah_f16x2{b0[2], b0[3]}));
+    *reinterpret_cast<uint2*>(rimg + (CH + r0 + 1) * AH_KROW + c4 * 4) =
+        make_uint2(__builtin_bit_cast(unsigned, ah_f16x2{b1[0], b1[1]}), __builtin_bit_cast(unsigned, ah_f16x2{b1[2], b1[3]}));
   }
 }
 // a lane's fragment of its own row: 4 chunks of 16 d, 8 consecutive d per lane half
@@ -337,9 +347,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_h3_kernel(const float* __
 #pragma unroll 1
   for (int k0 = 0; k0 < L; k0 += CH) {
     __syncthreads();
-    ah_fill_rows(Kh, CH, base + (long)k0 * rs + 64, rs, sc, tid, 64 * NW);
+    ah_fill_both(Kh, Kt, CH, base + (long)k0 * rs + 64, rs, sc, tid, 64 * NW);
     ah_fill_rows(Vh, CH, base + (long)k0 * rs + 128, rs, sc, tid, 64 * NW);
-    ah_fill_transposed(Kt, CH, base + (long)k0 * rs + 64, rs, sc, tid, 64 * NW);
     __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < CH / 32; ++kt) {
@@ -387,10 +396,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_h3_kernel(const float* _
   for (int q0 = 0; q0 < L; q0 += CH) {
     __syncthreads();
     const float* gsrc = dout + ((long)b * L + q0) * ro + h * 64;
-    ah_fill_rows(Qh, CH, base + (long)q0 * rs, rs, sc, tid, 64 * NW);
-    ah_fill_rows(Gh, CH, gsrc, ro, sg, tid, 64 * NW);
-    ah_fill_transposed(Qt, CH, base + (long)q0 * rs, rs, sc, tid, 64 * NW);
-    ah_fill_transposed(Gt, CH, gsrc, ro, sg, tid, 64 * NW);
+    ah_fill_both(Qh, Qt, CH, base + (long)q0 * rs, rs, sc, tid, 64 * NW);
+    ah_fill_both(Gh, Gt, CH, gsrc, ro, sg, tid, 64 * NW);
     for (int i = tid; i < CH; i += 64 * NW) {
       Ls[i] = lse[((long)b * heads + h) * L + q0 + i];
       Ls[CH + i] = delta[((long)b * heads + h) * L + q0 + i];
