@@ -47,15 +47,21 @@ __global__ void up2x_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, 
 // ---------------------------------------------------------------- layout / preconditioning
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const T* __restrict__ x, const float* __restrict__ mul, long mul_bstride,
-                                    float* __restrict__ y, int B, int C, int HW, int Cpad) {
+                                    float* __restrict__ y, int B, int C, int HW, int Cpad, float* __restrict__ amax) {
   long total = (long)B * HW;
+  float am = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int p = i % HW;
     int b = i / HW;
     float m = mul ? mul[b * mul_bstride] : 1.f;
     float* o = y + i * Cpad;
-    for (int c = 0; c < Cpad; ++c) o[c] = c < C ? m * (float)x[((long)b * C + c) * HW + p] : 0.f;
+    for (int c = 0; c < Cpad; ++c) {
+      const float v = c < C ? m * (float)x[((long)b * C + c) * HW + p] : 0.f;
+      am = fmaxf(am, fabsf(v));
+      o[c] = v;
+    }
   }
+  adm_amax_commit(am, amax);      // (amax may be null) bound vector of the UNet's input: the stem conv then runs on the fp16 format
 }
 template <typename T>
 __global__ void precond_out_kernel(const T* __restrict__ x, const float* __restrict__ f, int ldf,
@@ -73,15 +79,21 @@ __global__ void precond_out_kernel(const T* __restrict__ x, const float* __restr
   }
 }
 __global__ void precond_out_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ s, long cbs,
-                                       float* __restrict__ df, int ldf, int B, int C, int HW) {
+                                       float* __restrict__ df, int ldf, int B, int C, int HW, float* __restrict__ amax) {
   long total = (long)B * HW;
+  float am = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int p = i % HW;
     int b = i / HW;
     float sv = s[b * cbs];
     float* o = df + i * ldf;
-    for (int c = 0; c < ldf; ++c) o[c] = c < C ? sv * dout[((long)b * C + c) * HW + p] : 0.f;
+    for (int c = 0; c < ldf; ++c) {
+      const float v = c < C ? sv * dout[((long)b * C + c) * HW + p] : 0.f;
+      am = fmaxf(am, fabsf(v));
+      o[c] = v;
+    }
   }
+  adm_amax_commit(am, amax);      // (amax may be null) bound vector of the output conv's dy
 }
 template <typename T>
 __global__ void axpby_b_kernel(const T* __restrict__ x, const float* __restrict__ y, const float* __restrict__ a,
@@ -632,9 +644,21 @@ extern "C" int adm_nchw_to_nhwc(const void* x, int x_is_f64, const float* mul, l
   if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || Cpad < C) return ADM_EINVAL;
   int grid = ew_grid((long)B * HW);
   if (x_is_f64)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)x, mul, mul_bstride, y, B, C, HW, Cpad);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)x, mul, mul_bstride, y, B, C, HW, Cpad, static_cast<float*>(nullptr));
   else
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, mul, mul_bstride, y, B, C, HW, Cpad);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, mul, mul_bstride, y, B, C, HW, Cpad, static_cast<float*>(nullptr));
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+// ... that also raises the bound vector amax (include/adm_hip.h) to max |y|
+extern "C" int adm_nchw_to_nhwc_amax(const void* x, int x_is_f64, const float* mul, long mul_bstride, float* y, float* amax, int B, int C,
+                                     int HW, int Cpad, hipStream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || Cpad < C) return ADM_EINVAL;
+  int grid = ew_grid((long)B * HW);
+  if (x_is_f64)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)x, mul, mul_bstride, y, B, C, HW, Cpad, amax);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, mul, mul_bstride, y, B, C, HW, Cpad, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -654,7 +678,16 @@ extern "C" int adm_precond_out(const void* x, int x_is_f64, const float* f, int 
 extern "C" int adm_precond_out_bwd(const float* dout, const float* s, long coef_bstride, float* df, int ldf, int B,
                                    int C, int HW, hipStream_t stream) {
   if (!dout || !s || !df || B <= 0 || C <= 0 || HW <= 0 || ldf < C) return ADM_EINVAL;
-  hipLaunchKernelGGL(precond_out_bwd_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, stream, dout, s, coef_bstride, df, ldf, B, C, HW);
+  hipLaunchKernelGGL(precond_out_bwd_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, stream, dout, s, coef_bstride, df, ldf, B, C, HW,
+                     static_cast<float*>(nullptr));
+  ADM_CHECK_LAUNCH();
+  return ADM_OK;
+}
+// ... that also raises the bound vector amax to max |df|
+extern "C" int adm_precond_out_bwd_amax(const float* dout, const float* s, long coef_bstride, float* df, int ldf, float* amax, int B,
+                                        int C, int HW, hipStream_t stream) {
+  if (!dout || !s || !df || B <= 0 || C <= 0 || HW <= 0 || ldf < C) return ADM_EINVAL;
+  hipLaunchKernelGGL(precond_out_bwd_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, stream, dout, s, coef_bstride, df, ldf, B, C, HW, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }

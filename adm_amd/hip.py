@@ -94,8 +94,10 @@ _SIGS = {
     "adm_attn_bwd_h3": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "adm_resample2x": [P, P, I, I, I, I, I, F, I, P],
     "adm_nchw_to_nhwc": [P, I, P, L, P, I, I, I, I, P],
+    "adm_nchw_to_nhwc_amax": [P, I, P, L, P, P, I, I, I, I, P],
     "adm_precond_out": [P, I, P, I, P, P, L, P, I, I, I, P],
     "adm_precond_out_bwd": [P, P, L, P, I, I, I, I, P],
+    "adm_precond_out_bwd_amax": [P, P, L, P, I, P, I, I, I, P],
     "adm_axpby_b": [P, I, P, P, P, L, P, I, L, P],
     "adm_pos_embedding": [P, P, I, I, P],
     "adm_silu_fwd": [P, P, L, P],

@@ -1725,11 +1725,19 @@ def spatial_att_gate(att, qk, h, xres):
 # ------------------------------------------------------------------------------------------------
 # layout + preconditioning
 # ------------------------------------------------------------------------------------------------
+_in_amax_out = None     # bound vector of the last _nchw_to_nhwc output (handed to nchw_to_nhwc(), as _gn_amax_out)
+
+
 def _nchw_to_nhwc(x, mul, cpad):
     B, C, H, W = x.shape
     y = _new((B, H, W, cpad), x)
     bs = 0 if (mul is None or mul.numel() == 1) else 1
-    call("adm_nchw_to_nhwc", ptr(x), int(x.dtype == torch.float64), ptr(mul), bs, ptr(y), B, C, H * W, cpad)
+    global _in_amax_out
+    _in_amax_out = slot = _amax_slot(x) if (FP16X3 and BF16X6 and COMPUTE == "f32" and x.is_cuda) else None
+    if slot is not None:        # the UNet's input with its bound: the stem conv and its weight gradient run on the fp16 format
+        call("adm_nchw_to_nhwc_amax", ptr(x), int(x.dtype == torch.float64), ptr(mul), bs, ptr(y), ptr(slot), B, C, H * W, cpad)
+    else:
+        call("adm_nchw_to_nhwc", ptr(x), int(x.dtype == torch.float64), ptr(mul), bs, ptr(y), B, C, H * W, cpad)
     return y
 
 
@@ -1762,9 +1770,14 @@ def nchw_to_nhwc(x: torch.Tensor, mul: Optional[torch.Tensor], cpad: int) -> tor
     if x.dtype not in (torch.float32, torch.float64):
         x = x.to(torch.float32)
     x = x if x.is_contiguous() else x.contiguous()
+    global _in_amax_out
     if torch.is_grad_enabled() and x.requires_grad:
-        return _NchwToNhwc.apply(x, None if mul is None else mul.detach(), cpad)
-    return _nchw_to_nhwc(x, mul, cpad)
+        y = _NchwToNhwc.apply(x, None if mul is None else mul.detach(), cpad)
+    else:
+        y = _nchw_to_nhwc(x, mul, cpad)
+    if _in_amax_out is not None:
+        y._adm_amax, _in_amax_out = _in_amax_out, None
+    return y
 
 
 class _PrecondOut(torch.autograd.Function):
@@ -1790,7 +1803,12 @@ class _PrecondOut(torch.autograd.Function):
         df = dx = None
         if ctx.needs_input_grad[0]:
             df = _new((B, H, W, ldf), dout)
-            call("adm_precond_out_bwd", ptr(dout), ptr(s), cbs, ptr(df), ldf, B, C, H * W)
+            slot = _amax_slot(dout) if (FP16X3 and BF16X6 and COMPUTE == "f32") else None
+            if slot is not None:    # the output conv's dy with its bound: its data and weight gradients run on the fp16 format
+                call("adm_precond_out_bwd_amax", ptr(dout), ptr(s), cbs, ptr(df), ldf, ptr(slot), B, C, H * W)
+                _reg_amax(df, slot)
+            else:
+                call("adm_precond_out_bwd", ptr(dout), ptr(s), cbs, ptr(df), ldf, B, C, H * W)
         if ctx.needs_input_grad[1]:          # the skip path c_skip * x (uncond_unet.py:631-632)
             dx = _like(dout)
             call("adm_axpby_b", None, 0, ptr(dout), None, ptr(a), cbs, ptr(dx), B, dout.numel() // B)

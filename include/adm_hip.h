@@ -364,6 +364,9 @@ int adm_resample2x(const float* x, float* y, int B, int H, int W, int C, int mod
  * EDMPrecond's `c_in * x` + .to(float32) (uncond_unet.py:616, 628) fused with NCHW->NHWC. */
 int adm_nchw_to_nhwc(const void* x, int x_is_f64, const float* mul, long mul_bstride, float* y, int B, int C, int HW,
                      int Cpad, hipStream_t stream);
+/* ... that also raises the bound vector amax to max |y| (the stem conv then runs on the fp16 format) */
+int adm_nchw_to_nhwc_amax(const void* x, int x_is_f64, const float* mul, long mul_bstride, float* y, float* amax, int B, int C, int HW,
+                          int Cpad, hipStream_t stream);
 /* out_nchw[b,c,p] = a[b] * x_nchw[b,c,p] + s[b] * f_nhwc[b,p,c]   (D = c_skip x + c_out F, :631-632).
  * x == NULL (then a may be NULL): out = s[b] * f -- the adjoint of adm_nchw_to_nhwc, i.e. dL/dx through `c_in * x` (the tensors
  * EDMPrecond.forward returns take part in autograd w.r.t. x, uncond_unet.py:614-635). */
@@ -372,6 +375,9 @@ int adm_precond_out(const void* x, int x_is_f64, const float* f, int ldf, const 
 /* backward of the two above w.r.t. f:  df_nhwc[b,p,c<C] = s[b] * dout_nchw[b,c,p], zero for c >= C */
 int adm_precond_out_bwd(const float* dout, const float* s, long coef_bstride, float* df, int ldf, int B, int C,
                         int HW, hipStream_t stream);
+/* ... that also raises the bound vector amax to max |df| (the output conv's gradients then run on the fp16 format) */
+int adm_precond_out_bwd_amax(const float* dout, const float* s, long coef_bstride, float* df, int ldf, float* amax, int B, int C,
+                             int HW, hipStream_t stream);
 /* emb[b][0:C/2] = cos(t[b] f_i), emb[b][C/2:] = sin(t[b] f_i), f_i = (1/10000)^(i/(C/2))
  * (PositionalEmbedding, uncond_unet.py:224-230) */
 int adm_pos_embedding(const float* t, float* emb, int B, int C, hipStream_t stream);
