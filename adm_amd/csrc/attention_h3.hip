@@ -12,7 +12,8 @@
 //     every group of 16 permuted into the order in which the accumulator layout of S^T hands them out (lane half 0 holds rows
 //     0-3, 8-11 of a 16-row group, half 1 rows 4-7, 12-15) -- P^T then is the B operand as it stands, no cross-lane move;
 //   * P in [0, 1] is split with the fixed scale 2^14.
-// L <= 256, L % 32 == 0 (the UNet's 8x8 / 16x16 attention levels); anything else stays on attention.hip.
+// L in {32, 64, 128, 256} (the UNet's attention levels) or a multiple of 256 (the latent configs' 32x32 level: 256-key chunks, online
+// softmax); anything else stays on attention.hip.
 #include "common.h"
 #include "../../include/adm_hip.h"
 
@@ -47,7 +48,9 @@ __device__ __forceinline__ void ah_split8(const float (&v)[8], float s, ah_u32x4
   t1 = ah_u32x4{b[0], b[1], b[2], b[3]};
 }
 
-template <int NKT>
+// MULTI: L is a multiple of 256; gridDim.y = the 256-query chunk this workgroup owns, the keys pass through LDS 256 at a time with a
+// running max / sum per query (online softmax), as attention.hip does for its long sequences
+template <int NKT, bool MULTI>
 __global__ __launch_bounds__(64 * NKT) void attn_fwd_h3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                 float* __restrict__ lse, int L, int heads,
                                                                 const float* __restrict__ amax) {
@@ -61,10 +64,33 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_h3_kernel(const float* __re
   const long rs = (long)heads * 192;
   const float* base = qkv + (long)b * L * rs + h * 192;
   const float sc = ah_scale(adm_amax_read(amax));
+  // ---- the query fragment of this lane: 4 chunks of 16 d, 8 consecutive d per lane half; pre-scaled by 1/8 (exact)
+  const int q = (MULTI ? (int)blockIdx.y * CH : 0) + wid * 32 + lr;
+  ah_u32x4 q0[4], q1[4];
+  {
+    const float* qrow = base + (long)q * rs;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(qrow + 16 * c + 8 * lh);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(qrow + 16 * c + 8 * lh + 4);
+      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      ah_split8(v, sc * 0.125f, q0[c], q1[c]);
+    }
+  }
+  const float inv_s = 1.f / (sc * sc);
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  const int nchunks = MULTI ? L / CH : 1;
+#pragma unroll 1
+  for (int kc = 0; kc < nchunks; ++kc) {
+  const float* kbase = base + (long)kc * CH * rs;
+  if (MULTI) __syncthreads();                        // the previous chunk's images are fully consumed
   // ---- K -> two fp16 images, rows as they are
   for (int i = tid; i < CH * 16; i += 64 * NKT) {
     const int key = i >> 4, c4 = i & 15;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)key * rs + 64 + c4 * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(kbase + (long)key * rs + 64 + c4 * 4);
     unsigned t0[2], t1[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -82,8 +108,8 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_h3_kernel(const float* __re
     const int grp = kp >> 3, p0 = (kp & 7) * 2;      // positions p0, p0 + 1 of group grp
     // inverse of ah_pos16 for position p: half = p >> 3, i = p & 7 -> key = (i & 3) + 8 (i >> 2) + 4 half
     const int k0 = grp * 16 + ((p0 & 7) & 3) + 8 * ((p0 & 7) >> 2) + 4 * (p0 >> 3);
-    const f32x4 va = *reinterpret_cast<const f32x4*>(base + (long)k0 * rs + 128 + c4 * 4);
-    const f32x4 vb = *reinterpret_cast<const f32x4*>(base + (long)(k0 + 1) * rs + 128 + c4 * 4);      // position p0 + 1 = key k0 + 1 (p0 even)
+    const f32x4 va = *reinterpret_cast<const f32x4*>(kbase + (long)k0 * rs + 128 + c4 * 4);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(kbase + (long)(k0 + 1) * rs + 128 + c4 * 4);      // position p0 + 1 = key k0 + 1 (p0 even)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float x0 = va[j] * sc, x1 = vb[j] * sc;
@@ -94,22 +120,8 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_h3_kernel(const float* __re
           __builtin_bit_cast(unsigned, ah_f16x2{(_Float16)(x0 - (float)h00), (_Float16)(x1 - (float)h01)});
     }
   }
-  // ---- the query fragment of this lane: 4 chunks of 16 d, 8 consecutive d per lane half; pre-scaled by 1/8 (exact)
-  const int q = wid * 32 + lr;
-  ah_u32x4 q0[4], q1[4];
-  {
-    const float* qrow = base + (long)q * rs;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(qrow + 16 * c + 8 * lh);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(qrow + 16 * c + 8 * lh + 4);
-      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      ah_split8(v, sc * 0.125f, q0[c], q1[c]);
-    }
-  }
   __syncthreads();
   // ---- S^T tiles: keys on the accumulator rows, this lane's query on the column
-  const float inv_s = 1.f / (sc * sc);
   f32x16 s[NKT];
   float mc = -INFINITY;
 #pragma unroll
@@ -134,19 +146,23 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_h3_kernel(const float* __re
     }
   }
   mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
-  float l = 0.f;
+  const float mn = fmaxf(m, mc);
+  if constexpr (MULTI) {
+    const float rsc = (m == -INFINITY) ? 0.f : __expf(m - mn);       // rescale of what has been accumulated so far
+    l *= rsc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= rsc; o[1][r] *= rsc; }
+  }
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __expf(s[kt][r] - mc);
+      const float e = __expf(s[kt][r] - mn);
       s[kt][r] = e;
       l += e;
     }
+  m = mn;
   // ---- O^T = V^T P^T: d on the accumulator rows, the query on the lane
-  f32x16 o[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -166,6 +182,8 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_h3_kernel(const float* __re
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, o[db], 0, 0, 0);
       }
     }
+  }
+  const float mc = m;
   l += __shfl_xor(l, 32, 64);                          // the two wave halves hold disjoint keys of the same query
   // out^T accumulators (d on rows, the query on the lane) -> 16-byte pieces of the query's row
   const float oscale = 1.f / (l * sc * 16384.f);
@@ -180,17 +198,17 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_h3_kernel(const float* __re
   if (lh == 0 && lse) lse[((long)b * heads + h) * L + q] = mc + __logf(l);
 }
 
-template <int NKT>
+template <int NKT, bool MULTI>
 int launch_fwd_h3(const float* qkv, float* out, float* lse, const float* amax, int B, int L, int heads, hipStream_t st) {
   constexpr int CH = NKT * 32;
   constexpr int smem = (2 * CH * AH_KROW + 2 * 64 * (CH + 8)) * (int)sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_h3_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_h3_kernel<NKT, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return ADM_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_fwd_h3_kernel<NKT>), dim3(B * heads), dim3(64 * NKT), smem, st, qkv, out, lse, L, heads, amax);
+  hipLaunchKernelGGL((attn_fwd_h3_kernel<NKT, MULTI>), dim3(B * heads, MULTI ? L / CH : 1), dim3(64 * NKT), smem, st, qkv, out, lse, L, heads, amax);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
 }
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_h3_kernel(const float* __
   const float* base = qkv + (long)b * L * rs + h * 192;
   const float aq = adm_amax_read(amax_qkv), ag = adm_amax_read(amax_g);
   const float sc = ah_scale(aq), sg = ah_scale(ag), sd = ah_scale(128.f * aq * ag);
-  const int q = wid * 32 + lr;
+  const int q = (int)blockIdx.y * 32 * NW + wid * 32 + lr;      // (gridDim.y = L / 256 for the long sequences)
   ah_u32x4 q0[4], q1[4], g0[4], g1[4];
   ah_row_frag(base + (long)q * rs, lh, sc * 0.125f, q0, q1);
   const float* grow = dout + ((long)b * L + q) * ro + h * 64;
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_h3_kernel(const float* _
   const float* base = qkv + (long)b * L * rs + h * 192;
   const float aq = adm_amax_read(amax_qkv), ag = adm_amax_read(amax_g);
   const float sc = ah_scale(aq), sg = ah_scale(ag), sd = ah_scale(128.f * aq * ag);
-  const int key = wid * 32 + lr;
+  const int key = (int)blockIdx.y * 32 * NW + wid * 32 + lr;
   ah_u32x4 k0f[4], k1f[4], v0f[4], v1f[4];
   ah_row_frag(base + (long)key * rs + 64, lh, sc * 0.125f, k0f, k1f);
   ah_row_frag(base + (long)key * rs + 128, lh, sc, v0f, v1f);
@@ -439,9 +457,10 @@ int launch_bwd_h3(const float* qkv, const float* out, const float* dout, const f
       return ADM_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_dq_h3_kernel<NW>), dim3(B * heads), dim3(64 * NW), smem_dq, st, qkv, out, dout, lse, dqkv, delta, L, heads,
+  const dim3 grid(B * heads, L / (32 * NW));
+  hipLaunchKernelGGL((attn_bwd_dq_h3_kernel<NW>), grid, dim3(64 * NW), smem_dq, st, qkv, out, dout, lse, dqkv, delta, L, heads,
                      amax_qkv, amax_g, amax_out);
-  hipLaunchKernelGGL((attn_bwd_dkv_h3_kernel<NW>), dim3(B * heads), dim3(64 * NW), smem_dkv, st, qkv, dout, lse, delta, dqkv, L, heads,
+  hipLaunchKernelGGL((attn_bwd_dkv_h3_kernel<NW>), grid, dim3(64 * NW), smem_dkv, st, qkv, dout, lse, delta, dqkv, L, heads,
                      amax_qkv, amax_g, amax_out);
   ADM_CHECK_LAUNCH();
   return ADM_OK;
@@ -450,7 +469,7 @@ int launch_bwd_h3(const float* qkv, const float* out, const float* dout, const f
 }  // namespace
 
 // adm_attn_bwd on the fp16 split format: amax_qkv / amax_dout = bound vectors of |qkv| and |dout|; amax_dqkv (may be NULL) = bound vector
-// raised to max |dqkv|.  L in {32, 64, 128, 256} (ADM_EINVAL otherwise); delta [B*heads][L] scratch as in adm_attn_bwd.
+// raised to max |dqkv|.  L as for adm_attn_fwd_h3; delta [B*heads][L] scratch as in adm_attn_bwd.
 extern "C" int adm_attn_bwd_h3(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
                                const float* amax_qkv, const float* amax_dout, float* amax_dqkv, int B, int L, int heads, hipStream_t stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || !delta || !amax_qkv || !amax_dout || B <= 0 || heads <= 0) return ADM_EINVAL;
@@ -460,7 +479,10 @@ extern "C" int adm_attn_bwd_h3(const float* qkv, const float* out, const float* 
     case 64: return launch_bwd_h3<2>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
     case 128: return launch_bwd_h3<4>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
     case 256: return launch_bwd_h3<8>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
-    default: return ADM_EINVAL;
+    default:
+      if (L > 256 && L % 256 == 0 && L <= 16384)
+        return launch_bwd_h3<8>(qkv, out, dout, lse, dqkv, delta, amax_qkv, amax_dout, amax_dqkv, B, L, heads, stream);
+      return ADM_EINVAL;
   }
 }
 
@@ -469,10 +491,12 @@ extern "C" int adm_attn_bwd_h3(const float* qkv, const float* out, const float* 
 extern "C" int adm_attn_fwd_h3(const float* qkv, float* out, float* lse, const float* amax, int B, int L, int heads, hipStream_t stream) {
   if (!qkv || !out || !amax || B <= 0 || heads <= 0 || ((uintptr_t)qkv & 15)) return ADM_EINVAL;
   switch (L) {
-    case 32: return launch_fwd_h3<1>(qkv, out, lse, amax, B, L, heads, stream);
-    case 64: return launch_fwd_h3<2>(qkv, out, lse, amax, B, L, heads, stream);
-    case 128: return launch_fwd_h3<4>(qkv, out, lse, amax, B, L, heads, stream);
-    case 256: return launch_fwd_h3<8>(qkv, out, lse, amax, B, L, heads, stream);
-    default: return ADM_EINVAL;
+    case 32: return launch_fwd_h3<1, false>(qkv, out, lse, amax, B, L, heads, stream);
+    case 64: return launch_fwd_h3<2, false>(qkv, out, lse, amax, B, L, heads, stream);
+    case 128: return launch_fwd_h3<4, false>(qkv, out, lse, amax, B, L, heads, stream);
+    case 256: return launch_fwd_h3<8, false>(qkv, out, lse, amax, B, L, heads, stream);
+    default:
+      if (L > 256 && L % 256 == 0 && L <= 16384) return launch_fwd_h3<8, true>(qkv, out, lse, amax, B, L, heads, stream);
+      return ADM_EINVAL;
   }
 }

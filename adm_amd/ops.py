@@ -1497,7 +1497,7 @@ class _Attention(torch.autograd.Function):
             raise RuntimeError(f"qkv has {C3} channels, expected {heads * 192}")
         out = _new((B, H, W, heads * 64), qkv)
         lse = _new((B * heads, L), qkv)
-        h3 = amax is not None and ATTN_H3 and FP16X3 and COMPUTE == "f32" and L in (32, 64, 128, 256)
+        h3 = amax is not None and ATTN_H3 and FP16X3 and COMPUTE == "f32" and (L in (32, 64, 128, 256) or (L % 256 == 0 and L <= 16384))
         with _Prof("attnh3" if h3 else "attn", 4.0 * L * L * 64 * B * heads):
             if h3:
                 call("adm_attn_fwd_h3", ptr(qkv), ptr(out), ptr(lse), ptr(amax), B, L, heads)

@@ -342,10 +342,10 @@ int adm_attn_fwd(const float* qkv, float* out, float* lse, int B, int L, int hea
 int adm_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
                  int B, int L, int heads, hipStream_t stream);
 /* adm_attn_fwd with both matrix products on the fp16 split format (attention_h3.hip: three fp16 MFMAs per f32 product, as
- * adm_conv_fwd_wino2d_h3): amax = bound vector of |qkv|; L in {32, 64, 128, 256} (ADM_EINVAL otherwise).  Same replacement (:205-208). */
+ * adm_conv_fwd_wino2d_h3): amax = bound vector of |qkv|; L in {32, 64, 128, 256} or a multiple of 256 (ADM_EINVAL otherwise).  Same replacement (:205-208). */
 int adm_attn_fwd_h3(const float* qkv, float* out, float* lse, const float* amax, int B, int L, int heads, hipStream_t stream);
 /* adm_attn_bwd on the same format: amax_qkv / amax_dout = bound vectors of |qkv| and |dout|, amax_dqkv (may be NULL) = bound vector
- * raised to max |dqkv|; L in {32, 64, 128, 256}.  Autograd of :205-208. */
+ * raised to max |dqkv|; L as above.  Autograd of :205-208. */
 int adm_attn_bwd_h3(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
                     const float* amax_qkv, const float* amax_dout, float* amax_dqkv, int B, int L, int heads, hipStream_t stream);
 /* ... that also raises the bound vector amax to max |dqkv| (the qkv conv's gradients then run on the fp16 format) */
